@@ -1,0 +1,162 @@
+"""``BatchData`` -- the edge-pair mini-batch handed to every layer; drop-in for the
+reference's src/batch.py on this path.
+
+Same constructor arguments and the same attributes the layers read
+(``merge_data``, ``merge_higher_level``, ``batch_gids``, ``pair_list``,
+``interaction_combo_nxgraph``, ``dataset``, ``is_train``, ``batch_interaction_inds``).
+The per-pair python work of src/batch.py:105-144 (look up graph, nx -> tensors,
+dedup, merge) is one vectorised gather from the pre-tensorised ``MoleculeStore``;
+negative sampling (src/batch.py:61-103) is vectorised rejection sampling with the
+same acceptance rules.
+"""
+
+import numpy as np
+import torch
+
+from .config import FLAGS
+
+__all__ = ["BatchData", "ordered_unique"]
+
+
+def ordered_unique(a):
+    """Unique values in order of first appearance (the insertion order of the
+    reference's ``graphs_in_batch`` dict: src/batch.py:131-136)."""
+    flat = np.asarray(a).reshape(-1)
+    _, idx = np.unique(flat, return_index=True)
+    return flat[np.sort(idx)]
+
+
+class _Pair(object):
+    """Lazy view of one pair's label / prediction (utils/data/graph.py GraphPair)."""
+
+    __slots__ = ("_batch", "_i")
+
+    def __init__(self, batch, i):
+        self._batch, self._i = batch, i
+
+    @property
+    def true_label(self):
+        return int(self._batch._labels[self._i])
+
+    def get_link_pred(self):
+        preds = getattr(self._batch, "pair_preds", None)
+        if preds is None:
+            raise ValueError('Must call assign_link_pred before calling this')
+        if self._batch._preds_host is None:
+            self._batch._preds_host = preds.detach().cpu().numpy()     # ONE sync for the batch
+        p = self._batch._preds_host[self._i]
+        return float(p[0]) if p.shape[0] == 1 else p
+
+
+class BatchData(object):
+    def __init__(self, batch_gids, dataset, sampled_gids=None, curr_sample_edge_type=None,
+                 is_train=True, ignore_pairs=False, enforce_negative_sampling=True,
+                 unique_graphs=True, subgraph=None, rng=None):
+        self.dataset = dataset
+        self.is_train = is_train
+        if isinstance(batch_gids, torch.Tensor):
+            batch_gids = batch_gids.cpu().numpy()
+        self.batch_gids = np.asarray(batch_gids).astype('int').reshape(-1, 2)
+        if hasattr(dataset, "interaction_combo_nxgraph"):
+            self.interaction_combo_nxgraph = dataset.interaction_combo_nxgraph
+            if not is_train:
+                self._snapshot_init_x()
+        self.unique_graphs = unique_graphs
+        self.positive_pair_gids = self.batch_gids
+        self.ignore_pairs = ignore_pairs
+        self.curr_sample_edge_type = curr_sample_edge_type
+        self._labels = None
+        self._preds_host = None
+        if getattr(FLAGS, "negative_sample", False) and is_train and not ignore_pairs:
+            assert sampled_gids is not None
+            self.sampled_gids = np.asarray(sampled_gids)
+            self.sample_negative_pairs(enforce_negative_sampling,
+                                       rng if rng is not None else np.random.default_rng())
+        self.merge_data, self.pair_list = self._merge_into_one_graph(self.batch_gids)
+        gs_map = self.dataset.gs_map
+        self.batch_interaction_inds = [gs_map[g] for g in self.batch_gids.flatten()]
+        self.merge_higher_level = {}
+        if subgraph is not None:
+            raise NotImplementedError("sampled subgraphs (use_sampled_subgraph) are outside the hot path")
+
+    # -- negatives: src/batch.py:61-103 ------------------------------------------------
+    def sample_negative_pairs(self, enforce_negative, rng):
+        gs_map = self.dataset.gs_map
+        want = len(self.batch_gids) * int(getattr(FLAGS, "num_negative_samples", 1))
+        pool = self.sampled_gids if getattr(FLAGS, "enforce_sampling_amongst_same_graphs", True) \
+            else np.asarray(list(gs_map.keys()))
+        n = len(self.sampled_gids)
+        if getattr(FLAGS, "enforce_sampling_amongst_same_graphs", True):
+            want = int(min(want, n * (n - 1) // 2 - len(self.batch_gids)))
+        pos = self.dataset.positive_pair_keys()
+        N = np.int64(self.dataset.num_graphs())
+        rows = np.vectorize(gs_map.get)
+        bp = rows(self.positive_pair_gids)
+        pos = np.union1d(pos, np.minimum(bp[:, 0], bp[:, 1]) * N + np.maximum(bp[:, 0], bp[:, 1]))
+        chosen, seen = [], set()
+        cursor = 0
+        while len(chosen) < want:
+            m = max(2 * (want - len(chosen)), 16)
+            a = self.sampled_gids[(cursor + np.arange(m)) % n]
+            cursor += m
+            b = rng.choice(pool, size=m)
+            if enforce_negative:
+                ra, rb = rows(a), rows(b)
+                key = np.minimum(ra, rb) * N + np.maximum(ra, rb)
+                ok = (a != b) & ~np.isin(key, pos)
+            else:
+                key = np.arange(m)
+                ok = np.ones(m, dtype=bool)
+            for x, y, k, good in zip(a, b, key, ok):
+                if good and (not enforce_negative or int(k) not in seen):
+                    seen.add(int(k))
+                    chosen.append((int(x), int(y)))
+                    if len(chosen) == want:
+                        break
+        if chosen:
+            self.negative_pair_gids = np.asarray(chosen)
+            self._neg_start = len(self.batch_gids)
+            self.batch_gids = np.concatenate((self.batch_gids, self.negative_pair_gids))
+
+    # -- merge: src/batch.py:105-144 + src/merged_graph.py --------------------------------
+    def _merge_into_one_graph(self, batch_gids):
+        store = self.dataset.molecules
+        if self.unique_graphs:
+            gids = ordered_unique(batch_gids).tolist()
+        else:
+            gids = batch_gids.reshape(-1).tolist()
+        merged = store.merge(gids, self.unique_graphs)
+        self._graph_gids = gids
+        if self.ignore_pairs:
+            return merged, []
+        labels = self.dataset.labels_of(self.positive_pair_gids)
+        n_neg = len(batch_gids) - len(self.positive_pair_gids)
+        self._labels = np.concatenate([labels, np.zeros(n_neg, dtype=np.int64)])
+        pair_list = [_Pair(self, i) for i in range(len(batch_gids))]
+        assert len(pair_list) == batch_gids.shape[0]
+        return merged, pair_list
+
+    def interaction_rows_of_batch_graphs(self):
+        """gs_map[gid] for every graph of the merged batch, int32 on the device."""
+        rows = getattr(self, "_graph_rows", None)
+        if rows is None:
+            gs_map = self.dataset.gs_map
+            rows = torch.as_tensor(np.asarray([gs_map[g] for g in self._graph_gids], dtype=np.int32))
+            rows = rows.to(self.merge_data['merge'].x.device)
+            self._graph_rows = rows
+        return rows
+
+    def true_labels(self):
+        return torch.as_tensor(self._labels).to(self.merge_data['merge'].x.device)
+
+    # -- eval-time snapshot of init_x: src/batch.py:146-162 ---------------------------------
+    def _snapshot_init_x(self):
+        g = self.interaction_combo_nxgraph
+        if isinstance(getattr(g, "init_x", None), torch.Tensor):
+            self.save_init_x = g.init_x
+            g.init_x = self.save_init_x.clone()
+
+    def restore_interaction_nxgraph(self):
+        g = self.dataset.interaction_combo_nxgraph
+        if isinstance(g.init_x, torch.Tensor):
+            g.init_x = self.save_init_x.detach() if hasattr(self, "save_init_x") else g.init_x.detach()

@@ -1,0 +1,150 @@
+"""``NodeEmbedding`` and ``Loss`` -- drop-ins for the reference's model/layers.py.
+
+Same constructor, same ``forward(ins, batch_data, model)``, same parameter names
+(GIN ``conv.nn.0/2.{weight,bias}`` + buffer ``conv.eps``; GAT ``conv.{weight,att,
+bias}``; GCN ``conv.{weight,bias}``; ``bn.*``; PReLU ``act.weight``), so a
+reference ``state_dict`` loads unchanged.  The forward is libblgnn kernels only:
+CSR gather/segment-reduce + fp32-MFMA transform with act and eval-BatchNorm fused
+into the epilogue.  Forward-only: the reference's ``act -> bn`` order and its GIN
+"shared act module" quirk (layers.py:26,29,55) are preserved.
+"""
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import FLAGS
+from .layers_util import create_act, act_name, DerivedCache, bn_affine, prelu_slopes
+
+__all__ = ["NodeEmbedding", "Loss", "GINConv", "GATConv", "GCNConv"]
+
+
+def _glorot(t):
+    bound = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+    with torch.no_grad():
+        t.uniform_(-bound, bound)
+
+
+class GINConv(nn.Module):
+    """Parameter holder shaped like torch_geometric.nn.GINConv(nn) 1.1.2."""
+
+    def __init__(self, mlps, eps=0.0):
+        super().__init__()
+        self.nn = mlps
+        self.register_buffer("eps", torch.tensor([float(eps)]))
+
+
+class GATConv(nn.Module):
+    """Parameter holder shaped like torch_geometric.nn.GATConv(in, out) 1.1.2
+    (heads=1, concat=True, negative_slope=0.2, dropout=0)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.negative_slope = 0.2
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels))
+        self.att = nn.Parameter(torch.empty(1, 1, 2 * out_channels))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        _glorot(self.weight)
+        _glorot(self.att)
+
+
+class GCNConv(nn.Module):
+    """Parameter holder shaped like torch_geometric.nn.GCNConv(in, out) 1.1.2."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        _glorot(self.weight)
+
+
+class NodeEmbedding(nn.Module):
+    def __init__(self, type, in_dim, out_dim, act, bn, normalize, higher_level=False,
+                 use_edge_attr=None):
+        super(NodeEmbedding, self).__init__()
+        self.normalize = normalize
+        self.type = type
+        self.out_dim = out_dim
+        self.higher_level = higher_level
+        assert higher_level if use_edge_attr and use_edge_attr != 'none' else True
+        self.use_edge_attr = use_edge_attr
+        if type == 'gcn':
+            self.conv = GCNConv(in_dim, out_dim)
+            self.act = create_act(act, out_dim)
+        elif type == 'gin':
+            self.act = create_act(act, out_dim)
+            self.conv = GINConv(nn.Sequential(
+                nn.Linear(in_dim, out_dim), self.act, nn.Linear(out_dim, out_dim)))
+        elif type == 'gat':
+            self.conv = GATConv(in_dim, out_dim)
+            self.act = create_act(act, out_dim)
+        else:
+            raise ValueError('Unknown node embedding layer type {}'.format(type))
+        self.bn = bn
+        if self.bn:
+            self.bn = torch.nn.BatchNorm1d(out_dim)
+        self._cache = DerivedCache()
+
+    def _graph(self, batch_data):
+        if self.higher_level:
+            return batch_data.merge_higher_level['merge']
+        return batch_data.merge_data['merge']
+
+    def forward(self, ins, batch_data, model, out=None):
+        """``out`` (optional) lets the caller place the result in a column slice of
+        a wider buffer (multi-scale readout / GMN f_node input)."""
+        ops.require_device(ins, "ins")
+        csr = self._graph(batch_data).csr()
+        act = act_name(self.act)
+        slopes = prelu_slopes(self._cache, "prelu", self.act, self.out_dim)
+        scale, shift = bn_affine(self._cache, "bn", self.bn)
+        with torch.no_grad():
+            if self.type == 'gin':
+                lin1, lin2 = self.conv.nn[0], self.conv.nn[2]
+                w1 = self._cache.get("w1", lambda w: w.t().contiguous(), lin1.weight)
+                w2 = self._cache.get("w2", lambda w: w.t().contiguous(), lin2.weight)
+                eps = self._cache.get("eps", lambda e: float(e[0]), self.conv.eps)
+                agg = ops.spmm_sum(csr, ins, self_coef=1.0 + eps, skip_self=True)
+                h = ops.linear(agg, w1, lin1.bias, act=act, act_param=slopes)
+                x = ops.linear(h, w2, lin2.bias, act=act, act_param=slopes,
+                               bn_scale=scale, bn_shift=shift, out=out)
+            elif self.type == 'gat':
+                x = ops.gat_conv(csr, ins, self.conv.weight, self.conv.att, self.conv.bias,
+                                 group=getattr(FLAGS, "gat_softmax_group", "src"),
+                                 slope=self.conv.negative_slope, act=act, act_param=slopes,
+                                 bn_scale=scale, bn_shift=shift, out=out)
+            else:
+                # layers.py:48-50 reads edge_attr of the LOWER merge even for upper layers;
+                # it is None in every shipped config, and only GCN would consume it.
+                edge_weight = getattr(batch_data.merge_data['merge'], "edge_attr", None)
+                x = ops.gcn_conv(csr, ins, self.conv.weight, self.conv.bias, edge_weight,
+                                 act=act, act_param=slopes, bn_scale=scale, bn_shift=shift, out=out)
+            model.store_layer_output(self, x)
+            if self.normalize:
+                x = ops.l2_normalize_rows(x)
+        return x
+
+
+class Loss(nn.Module):
+    """model/layers.py:66-89.  After the hot path; plain torch."""
+
+    def __init__(self, type):
+        super(Loss, self).__init__()
+        self.type = type
+        if type == 'BCE':
+            self.loss = nn.BCELoss()
+        elif type == 'BCEWithLogits':
+            self.loss = nn.BCEWithLogitsLoss()
+        elif type == 'CE':
+            self.loss = nn.CrossEntropyLoss()
+        else:
+            raise ValueError('Unknown loss layer type {}'.format(type))
+
+    def forward(self, ins, batch_data, _):
+        labels = batch_data.true_labels()
+        if self.type != 'CE':
+            return self.loss(ins.view(len(batch_data.batch_gids)), labels.float())
+        return self.loss(ins, labels.long())

@@ -1,0 +1,130 @@
+"""Node -> graph readout: drop-ins for the reference's model/layers_aggregation.py.
+
+``scatter_mean`` / ``scatter_add`` over the sorted batch vector become one
+segment-reduce kernel per pooled activation, each writing straight into its
+column slice of the concatenated output; with higher-level layers present the
+per-gid ``init_x`` row writes (layers_aggregation.py:68-74, a python loop of G
+indexed assignments) become one row-scatter kernel.
+"""
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import FLAGS
+from .layers_util import MLP
+
+__all__ = ["NodeAggregationPairs", "NodeAggregation", "DeepSets", "GMNAggregatorPairs"]
+
+
+def _segments(batch_data, pair_batch):
+    if pair_batch and hasattr(batch_data, "pair_batch"):
+        b = batch_data.pair_batch
+        return ops.segments_from_batch(b, int(batch_data.num_pairs))
+    return batch_data.merge_data['merge'].segments()
+
+
+class _SegmentPool(object):
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __call__(self, x, seg, out=None):
+        return ops.segment_reduce(seg, x, self.kind, out=out)
+
+
+class NodeAggregationPairs(nn.Module):
+    def __init__(self, style, concat_multi_scale=False, in_dim=None, out_dim=None,
+                 num_mlp_layers=None):
+        super().__init__()
+        self.style = style
+        self.concat_multi_scale = concat_multi_scale
+        if self.style == "avg_pool":
+            self.agg_func = _SegmentPool("mean")
+        elif self.style == "sum":
+            self.agg_func = _SegmentPool("sum")
+        elif self.style == 'deepsets':
+            self.agg_func = DeepSets(in_dim, out_dim, num_mlp_layers)
+        elif self.style == 'gmn_aggr':
+            self.agg_func = GMNAggregatorPairs(in_dim, out_dim, bn=True)
+        else:
+            raise NotImplementedError("{} is not implemented".format(style))
+
+    def forward(self, ins, batch_data, model, pair_batch=False):
+        ops.require_device(ins, "ins")
+        seg = _segments(batch_data, pair_batch)
+        with torch.no_grad():
+            if self.concat_multi_scale:
+                if 'gmn' not in FLAGS.model:
+                    xs = model.acts[1:]
+                else:
+                    xs = [x for i, x in enumerate(model.acts[1:]) if i % 2 == 1]
+                if isinstance(self.agg_func, _SegmentPool):
+                    G = seg.numel() - 1
+                    widths = [x.shape[1] for x in xs]
+                    out = torch.empty((G, sum(widths)), dtype=torch.float32, device=ins.device)
+                    c = 0
+                    for x, w in zip(xs, widths):
+                        self.agg_func(x, seg, out=out[:, c:c + w])
+                        c += w
+                else:
+                    out = torch.cat([self.agg_func(x, seg) for x in xs], dim=1)
+            else:
+                out = self.agg_func(ins, seg)
+        return out
+
+
+class DeepSets(nn.Module):
+    """layers_aggregation.py:45-56."""
+
+    def __init__(self, in_dim, out_dim, num_mlp_layers):
+        super(DeepSets, self).__init__()
+        self.phi = MLP(in_dim, out_dim, num_hidden_lyr=num_mlp_layers - 1)
+        self.rho = MLP(out_dim, out_dim, num_hidden_lyr=num_mlp_layers - 1)
+
+    def forward(self, ins, seg, out=None):
+        return self.rho(ops.segment_reduce(seg, self.phi(ins), "mean"), out=out)
+
+
+class NodeAggregation(NodeAggregationPairs):
+    """aggregates node embeddings for a graph embedding (one unique embedding per graph)"""
+
+    def __init__(self, style, is_last_layer, **kwargs):
+        super(NodeAggregation, self).__init__(style, **kwargs)
+        self.is_last_layer = is_last_layer
+
+    def forward(self, x, batch_data, model, pair_batch=False):
+        out = super().forward(x, batch_data, model, pair_batch)
+        if not FLAGS.higher_level_layers:
+            return out
+        # layers_aggregation.py:68-74: init_x[gs_map[gid]] = out[ind], as one kernel
+        graph = batch_data.interaction_combo_nxgraph
+        rows = batch_data.interaction_rows_of_batch_graphs()
+        init_x = graph.init_x
+        if not isinstance(init_x, torch.Tensor) or init_x.shape[1] != out.shape[1]:
+            init_x = torch.zeros((graph.number_of_nodes(), out.shape[1]), dtype=torch.float32,
+                                 device=out.device)
+            graph.init_x = init_x
+        ops.scatter_rows(out, rows, init_x)
+        return out
+
+
+class GMNAggregatorPairs(nn.Module):
+    """layers_aggregation.py:78-95."""
+
+    def __init__(self, input_dim, output_dim, bn):
+        super().__init__()
+        self.out_dim = output_dim
+        self.sigmoid = nn.Sigmoid()
+        self.weight_func = MLP(input_dim, output_dim, num_hidden_lyr=1,
+                               hidden_channels=[output_dim], bn=bn)
+        self.gate_func = MLP(input_dim, output_dim, num_hidden_lyr=1,
+                             hidden_channels=[output_dim], bn=bn)
+        self.mlp_graph = MLP(output_dim, output_dim, num_hidden_lyr=1,
+                             hidden_channels=[output_dim], bn=bn)
+
+    def forward(self, x, seg, out=None):
+        weighted_x = self.weight_func(x)
+        gated_x = torch.sigmoid(self.gate_func(x))      # elementwise glue; non-default style
+        graph_embeddings = ops.segment_reduce(seg, gated_x * weighted_x, "sum")
+        return self.mlp_graph(graph_embeddings, out=out)

@@ -1,0 +1,86 @@
+"""``GMNPropagator`` -- drop-in for the reference's model/layers_gmn.py.
+
+What changes underneath (results equal to fp32 rounding):
+  * message:  m_sum_i = sum_e f_message(cat(x_i, x_j)).  f_message is
+    Linear(2D,2D) -> relu -> Linear(2D,2D) with NO activation after the last
+    Linear (layers_util.py:48-49), so the sum over edges commutes with it:
+        m_sum_i = W2 . ( sum_e relu(W1a x_i + W1b x_j + b1) ) + deg_i * b2
+    The E x 2D message tensor and the two per-edge GEMMs disappear: one node-level
+    GEMM (x -> [P|Q], N=4D), one edge kernel (sum_e relu(P_i + Q_j)) and one
+    node-level GEMM with a rank-1 (deg_i * b2) term.
+  * match: the python loop over pairs (layers_gmn.py:60-70, ~12 tiny kernels per
+    pair, an n1 x n2 x D temporary, S recomputed for the mirror) is one kernel.
+  * f_node input cat(x, m_sum, u_sum) is never concatenated: producers write
+    straight into column slices of one [Nn, 4D] buffer.
+"""
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .layers_util import MLP, DerivedCache
+
+__all__ = ["GMNPropagator"]
+
+
+class GMNPropagator(nn.Module):
+    def __init__(self, input_dim, output_dim, distance_metric='cosine', f_node='MLP'):
+        super().__init__()
+        self.out_dim = output_dim
+        self.input_dim = input_dim
+        if distance_metric == 'cosine':
+            self.distance_metric = nn.CosineSimilarity()
+        elif distance_metric == 'euclidean':
+            self.distance_metric = nn.PairwiseDistance()
+        # (sic) the reference's attribute name, kept for state-dict compatibility
+        self.f_messasge = MLP(2 * input_dim, 2 * input_dim, num_hidden_lyr=1,
+                              hidden_channels=[2 * input_dim])
+        self.f_node_name = f_node
+        if f_node == 'MLP':
+            self.f_node = MLP(4 * input_dim, output_dim, num_hidden_lyr=1, bn=True)
+        elif f_node == 'GRU':
+            self.f_node = nn.GRUCell(3 * input_dim, input_dim)
+        else:
+            raise ValueError("{} for f_node has not been implemented".format(f_node))
+        self._cache = DerivedCache()
+
+    def _message_weights(self):
+        D = self.input_dim
+        lin1, lin2 = self.f_messasge.layers[0], self.f_messasge.layers[1]
+
+        def split(w, b):
+            # [x_i | x_j] @ W1^T  ==  x_i @ W1[:, :D]^T + x_j @ W1[:, D:]^T ; bias rides on P
+            wpq = torch.cat([w[:, :D].t(), w[:, D:].t()], dim=1).contiguous()        # [D, 4D]
+            bpq = torch.cat([b, torch.zeros_like(b)]).contiguous()                   # [4D]
+            return wpq, bpq
+
+        wpq, bpq = self._cache.get("pq", split, lin1.weight, lin1.bias)
+        w2 = self._cache.get("w2", lambda w: w.t().contiguous(), lin2.weight)
+        return wpq, bpq, w2, lin2.bias
+
+    def forward(self, ins, batch_data, model, edge_index=None):
+        ops.require_device(ins, "ins")
+        if self.f_node_name != 'MLP':
+            raise NotImplementedError("f_node='GRU' is a non-default variant outside the hot path")
+        x = ins
+        merge = batch_data.merge_data['merge']
+        if edge_index is not None and edge_index is not merge.edge_index:
+            csr = ops.csr_from_edge_index(edge_index, x.shape[0])
+        else:
+            csr = merge.csr()
+        n, D = x.shape
+        with torch.no_grad():
+            wpq, bpq, w2, b2 = self._message_weights()
+            pq = ops.linear(x, wpq, bpq)                                  # [n, 4D] = [P | Q]
+            h = ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:])      # [n, 2D]
+            f_in = torch.empty((n, 4 * D), dtype=torch.float32, device=x.device)
+            f_in[:, :D].copy_(x)
+            ops.linear(h, w2, None, rowvec=ops.row_degree(csr), rowvec_w=b2, out=f_in[:, D:3 * D])
+            ops.gmn_match(merge.segments(), x, out=f_in[:, 3 * D:])
+            out = self.f_node(f_in)
+        model.store_layer_output(self, out)
+        return out
+
+    def f_match(self, x, batch_data):
+        """layers_gmn.py:55-72 as a single kernel (kept as a method for callers)."""
+        return ops.gmn_match(batch_data.merge_data['merge'].segments(), x)

@@ -1,0 +1,78 @@
+"""``LinkPred`` -- drop-in for model/layers_link_pred.py (the pair scorer that
+consumes the path's output).  normalize + gather + concat is one kernel, the MLP
+runs on the fp32 matrix cores, and the B per-pair ``.item()`` device syncs of
+layers_link_pred.py:69-70 / utils/data/graph.py:35-39 are replaced by one tensor
+(``batch_data.pair_preds``); ``pair.get_link_pred()`` reads it lazily.
+"""
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import FLAGS
+from .layers_util import MLP
+
+__all__ = ["LinkPred"]
+
+
+class LinkPred(nn.Module):
+    def __init__(self, type, mlp_dim, num_labels, weight_dim=None, batch_unique_graphs=True,
+                 multi_label_pred=False):
+        super().__init__()
+        self.type = type
+        self.num_labels = num_labels
+        self.batch_unique_graphs = batch_unique_graphs
+        self.weight_dim = weight_dim
+        self.multi_label_pred = multi_label_pred
+        if weight_dim:
+            self.weight_matrix = nn.Parameter(torch.zeros((weight_dim, weight_dim)))
+            torch.nn.init.xavier_normal_(self.weight_matrix, gain=nn.init.calculate_gain('relu'))
+        if self.type not in ["dot_product", "mlp_concat"]:
+            raise NotImplementedError
+        if self.multi_label_pred:
+            assert self.type == 'ntn' or self.type == 'mlp_concat'
+        if self.type == 'mlp_concat':
+            out = num_labels if multi_label_pred else 1
+            dims = self._calc_mlp_dims(mlp_dim * 2, out, division=8)
+            self.mlp_concat = MLP(mlp_dim * 2, out, num_hidden_lyr=len(dims),
+                                  hidden_channels=dims, bn=False)
+
+    @staticmethod
+    def _calc_mlp_dims(mlp_dim, output_dim=1, division=2):
+        dim, dims = mlp_dim, []
+        while dim > output_dim:
+            dim = dim // division
+            dims.append(dim)
+        return dims[:-1]
+
+    def pair_row_ids(self, batch_data):
+        """layers_link_pred.py:46-54: which rows of ``ins`` each pair reads."""
+        batch_gids = batch_data.batch_gids
+        if isinstance(batch_gids, torch.Tensor):
+            batch_gids = batch_gids.cpu().numpy()
+        if self.batch_unique_graphs:
+            table = batch_data.dataset.gs_map if FLAGS.higher_level_layers \
+                else batch_data.merge_data['gids_to_batch_ind']
+            ids = np.vectorize(table.get)(batch_gids)
+        else:
+            ids = np.arange(batch_gids.shape[0] * batch_gids.shape[1]).reshape(batch_gids.shape)
+        return np.ascontiguousarray(ids, dtype=np.int64)
+
+    def forward(self, ins, batch_data, model):
+        ops.require_device(ins, "ins")
+        ids = getattr(batch_data, "_pair_row_ids", None)
+        if ids is None:
+            ids = torch.as_tensor(self.pair_row_ids(batch_data)).to(ins.device)
+            batch_data._pair_row_ids = ids
+        ids1, ids2 = ids[:, 0].contiguous(), ids[:, 1].contiguous()
+        with torch.no_grad():
+            cat = ops.pair_gather_normalize(ins, ids1, ids2)
+            if self.type == "mlp_concat":
+                pair_preds = self.mlp_concat(
+                    cat, final_act="identity" if self.multi_label_pred else "sigmoid")
+            else:
+                d = ins.shape[1]
+                pair_preds = torch.sigmoid((cat[:, :d] * cat[:, d:]).sum(dim=1))
+        batch_data.pair_preds = pair_preds
+        return pair_preds

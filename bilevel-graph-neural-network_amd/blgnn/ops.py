@@ -1,0 +1,251 @@
+"""Tensor-level wrappers over the C ABI (include/blgnn.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every
+arithmetic step is a libblgnn kernel.  All functions require CUDA(HIP) fp32
+tensors and raise on anything else -- there is deliberately no CPU path.
+"""
+
+import torch
+
+from . import _lib
+from ._lib import call, ACT_IDS, GAT_GROUP, REDUCE_MEAN, REDUCE_SUM
+
+__all__ = [
+    "CSR", "csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear",
+    "gat_conv", "gcn_conv", "segment_reduce", "gmn_match", "edge_relu_sum",
+    "row_degree", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
+    "require_device",
+]
+
+
+def require_device(t, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(
+            "blgnn: %s must live on an MI355X (cuda) device; the hot path has no CPU "
+            "fallback (got %s)" % (name, getattr(t, "device", type(t))))
+
+
+def _mat(t, name):
+    """fp32 row-major [rows, cols] view with unit column stride; returns (ptr, ld)."""
+    require_device(t, name)
+    if t.dtype != torch.float32 or t.dim() != 2:
+        raise ValueError("blgnn: %s must be a 2-D float32 tensor" % name)
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        raise ValueError("blgnn: %s must have unit column stride" % name)
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+    if ld < t.shape[1]:
+        raise ValueError("blgnn: %s rows overlap (stride %d < %d)" % (name, ld, t.shape[1]))
+    return t.data_ptr(), ld
+
+
+def _vec(t, name, dtype=torch.float32, optional=True):
+    if t is None:
+        if optional:
+            return None
+        raise ValueError("blgnn: %s is required" % name)
+    require_device(t, name)
+    if t.dtype != dtype or not t.is_contiguous():
+        raise ValueError("blgnn: %s must be contiguous %s" % (name, dtype))
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _act(name):
+    if name not in ACT_IDS:
+        raise ValueError("Unknown activation function {}".format(name))
+    return ACT_IDS[name]
+
+
+class CSR(object):
+    """int32 CSR on the device: row = aggregation target, col = sources."""
+
+    __slots__ = ("rowptr", "col", "n", "nnz", "_deg")
+
+    def __init__(self, rowptr, col, n, nnz):
+        self.rowptr, self.col, self.n, self.nnz = rowptr, col, int(n), int(nnz)
+        self._deg = None
+
+
+def csr_from_edge_index(edge_index, num_nodes, symmetric=True):
+    """edge_index: int64 [2, nnz] on the device (the reference layout).  With
+    ``symmetric`` (every graph on this path: model/layers_util.py:133) the CSR is
+    keyed by edge_index[0], which is already sorted -> no atomics, no row sort."""
+    require_device(edge_index, "edge_index")
+    if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError("blgnn: edge_index must be int64 [2, nnz]")
+    ei = edge_index.contiguous()
+    nnz = ei.shape[1]
+    key, nbr = (ei[0], ei[1]) if symmetric else (ei[1], ei[0])
+    dev = ei.device
+    rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+    work = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+    call("blgnn_csr_from_coo", key.data_ptr(), nbr.data_ptr(), nnz, num_nodes,
+         rowptr.data_ptr(), col.data_ptr(), work.data_ptr(), _stream())
+    return CSR(rowptr, col[:nnz], num_nodes, nnz)
+
+
+def segments_from_batch(batch, num_graphs):
+    require_device(batch, "batch")
+    if batch.dtype != torch.int64:
+        raise ValueError("blgnn: batch must be int64")
+    batch = batch.contiguous()
+    seg = torch.empty(num_graphs + 1, dtype=torch.int32, device=batch.device)
+    call("blgnn_segments_from_batch", batch.data_ptr(), batch.numel(), num_graphs,
+         seg.data_ptr(), _stream())
+    return seg
+
+
+def _out(out, rows, cols, like):
+    if out is None:
+        return torch.empty((rows, cols), dtype=torch.float32, device=like.device)
+    if tuple(out.shape) != (rows, cols):
+        raise ValueError("blgnn: out has shape %s, expected %s" % (tuple(out.shape), (rows, cols)))
+    return out
+
+
+def spmm_sum(csr, x, self_coef=0.0, skip_self=False, w=None, out=None):
+    xp, ldx = _mat(x, "x")
+    n, d = x.shape
+    if n != csr.n:
+        raise ValueError("blgnn: x has %d rows, graph has %d nodes" % (n, csr.n))
+    y = _out(out, n, d, x)
+    yp, ldy = _mat(y, "out")
+    call("blgnn_spmm_sum", csr.rowptr.data_ptr(), csr.col.data_ptr(), _vec(w, "w"), xp, ldx,
+         yp, ldy, n, d, float(self_coef), int(bool(skip_self)), _stream())
+    return y
+
+
+def linear(x, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn_shift=None,
+           rowvec=None, rowvec_w=None, out=None):
+    """epi(x @ w_kn + bias [+ rowvec (x) rowvec_w]); w_kn is [K, N] row-major."""
+    xp, ldx = _mat(x, "x")
+    wp, ldw = _mat(w_kn, "w")
+    M, K = x.shape
+    if w_kn.shape[0] != K:
+        raise ValueError("blgnn: x is [%d,%d] but w is [%d,%d]" % (M, K, w_kn.shape[0], w_kn.shape[1]))
+    N = w_kn.shape[1]
+    y = _out(out, M, N, x)
+    yp, ldy = _mat(y, "out")
+    call("blgnn_linear", xp, ldx, wp, ldw, yp, ldy, M, N, K, _vec(bias, "bias"),
+         _vec(rowvec, "rowvec"), _vec(rowvec_w, "rowvec_w"), _act(act), _vec(act_param, "act_param"),
+         _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), _stream())
+    return y
+
+
+def gat_conv(csr, x, weight, att, bias, group="src", slope=0.2, act="identity", act_param=None,
+             bn_scale=None, bn_shift=None, out=None, accumulate=False):
+    """GATConv(heads=1) + the caller's act / eval-BN epilogue."""
+    if group not in GAT_GROUP:
+        raise ValueError("softmax_group must be 'src' or 'dst'")
+    h = linear(x, weight)
+    n, d = h.shape
+    hp, ldh = _mat(h, "h")
+    stats = torch.empty((4, n), dtype=torch.float32, device=h.device)
+    s_dst, s_src, mx, den = (stats[i].data_ptr() for i in range(4))
+    attv = att.reshape(-1)
+    s = _stream()
+    call("blgnn_gat_scores", hp, ldh, _vec(attv, "att", optional=False), n, d, s_dst, s_src, s)
+    call("blgnn_gat_softmax_stats", csr.rowptr.data_ptr(), csr.col.data_ptr(), s_dst, s_src, n,
+         GAT_GROUP[group], float(slope), mx, den, s)
+    y = _out(out, n, d, h)
+    yp, ldy = _mat(y, "out")
+    call("blgnn_gat_aggregate", csr.rowptr.data_ptr(), csr.col.data_ptr(), hp, ldh, s_dst, s_src,
+         mx, den, GAT_GROUP[group], float(slope), yp, ldy, n, d, _vec(bias, "bias"), _act(act),
+         _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"),
+         int(bool(accumulate)), s)
+    return y
+
+
+def gcn_conv(csr, x, weight, bias, edge_weight=None, act="identity", act_param=None,
+             bn_scale=None, bn_shift=None, out=None):
+    h = linear(x, weight)
+    n, d = h.shape
+    hp, ldh = _mat(h, "h")
+    dis = torch.empty(n, dtype=torch.float32, device=h.device)
+    s = _stream()
+    wp = _vec(edge_weight, "edge_weight")
+    call("blgnn_gcn_deg_inv_sqrt", csr.rowptr.data_ptr(), csr.col.data_ptr(), wp, n,
+         dis.data_ptr(), s)
+    y = _out(out, n, d, h)
+    yp, ldy = _mat(y, "out")
+    call("blgnn_gcn_aggregate", csr.rowptr.data_ptr(), csr.col.data_ptr(), wp, dis.data_ptr(), hp,
+         ldh, yp, ldy, n, d, _vec(bias, "bias"), _act(act), _vec(act_param, "act_param"),
+         _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), s)
+    return y
+
+
+def segment_reduce(seg, x, kind="mean", out=None, row_map=None):
+    """scatter_mean / scatter_add over sorted segments; ``out`` may be a column
+    slice of a wider buffer and ``row_map`` (int32[G]) redirects output rows."""
+    xp, ldx = _mat(x, "x")
+    G = seg.numel() - 1
+    d = x.shape[1]
+    if out is None:
+        out = torch.empty((G, d), dtype=torch.float32, device=x.device)
+    op, ldo = _mat(out, "out")
+    if out.shape[1] != d:
+        raise ValueError("blgnn: out must have %d columns" % d)
+    call("blgnn_segment_reduce", _vec(seg, "seg", torch.int32, False), G, xp, ldx, d,
+         REDUCE_MEAN if kind == "mean" else REDUCE_SUM, op, ldo,
+         _vec(row_map, "row_map", torch.int32), _stream())
+    return out
+
+
+def gmn_match(seg, x, out=None):
+    xp, ldx = _mat(x, "x")
+    G = seg.numel() - 1
+    if G % 2:
+        raise ValueError("blgnn: gmn_match needs an even number of graphs (pairs)")
+    u = _out(out, x.shape[0], x.shape[1], x)
+    up, ldu = _mat(u, "out")
+    call("blgnn_gmn_match", _vec(seg, "seg", torch.int32, False), G // 2, xp, ldx, up, ldu,
+         x.shape[1], _stream())
+    return u
+
+
+def edge_relu_sum(csr, p, q, out=None):
+    pp, ldp = _mat(p, "p")
+    qp, ldq = _mat(q, "q")
+    n, d = p.shape
+    y = _out(out, n, d, p)
+    yp, ldy = _mat(y, "out")
+    call("blgnn_edge_relu_sum", csr.rowptr.data_ptr(), csr.col.data_ptr(), pp, ldp, qp, ldq, yp,
+         ldy, n, d, _stream())
+    return y
+
+
+def row_degree(csr):
+    if csr._deg is None:
+        deg = torch.empty(csr.n, dtype=torch.float32, device=csr.rowptr.device)
+        call("blgnn_row_degree", csr.rowptr.data_ptr(), csr.n, deg.data_ptr(), _stream())
+        csr._deg = deg
+    return csr._deg
+
+
+def pair_gather_normalize(z, ids1, ids2, eps=1e-12):
+    zp, ldz = _mat(z, "z")
+    B, d = ids1.numel(), z.shape[1]
+    out = torch.empty((B, 2 * d), dtype=torch.float32, device=z.device)
+    call("blgnn_pair_gather_normalize", zp, ldz, _vec(ids1, "ids1", torch.int64, False),
+         _vec(ids2, "ids2", torch.int64, False), B, d, float(eps), out.data_ptr(), 2 * d, _stream())
+    return out
+
+
+def l2_normalize_rows(x, eps=1e-12, out=None):
+    xp, ldx = _mat(x, "x")
+    y = _out(out, x.shape[0], x.shape[1], x)
+    yp, ldy = _mat(y, "out")
+    call("blgnn_l2_normalize_rows", xp, ldx, yp, ldy, x.shape[0], x.shape[1], float(eps), _stream())
+    return y
+
+
+def scatter_rows(src, row_map, dst):
+    sp, lds = _mat(src, "src")
+    dp, ldd = _mat(dst, "dst")
+    call("blgnn_scatter_rows", sp, lds, _vec(row_map, "row_map", torch.int32, False), dp, ldd,
+         src.shape[0], src.shape[1], _stream())
+    return dst

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Builds libblgnn.so for gfx950 (cross-compiles without a GPU).  Output stays in-tree
+# (bilevel-graph-neural-network_amd/lib/) so that it travels to the GPU box.
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="$here/../lib"
+mkdir -p "$out" "$here/obj"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function"
+pids=()
+for f in runtime graph_layout gather readout linear gmn_match; do
+  src="$here/$f.hip"; obj="$here/obj/$f.o"
+  if [[ ! -f "$obj" || "$src" -nt "$obj" || "$here/common.hpp" -nt "$obj" || "$here/../../include/blgnn.h" -nt "$obj" ]]; then
+    $HIPCC $FLAGS -c "$src" -o "$obj" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC "$here"/obj/*.o -o "$out/libblgnn.so"
+echo "built $out/libblgnn.so"

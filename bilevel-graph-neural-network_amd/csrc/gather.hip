@@ -1,0 +1,459 @@
+// CSR edge-gather -> wavefront segment-reduce kernels (HBM / L2 bound).
+//
+// One "row worker" = LG adjacent lanes of a 64-lane wavefront owns one output row
+// (LG = 16/32/64 chosen so that one float4 per lane covers the row when d <= 256;
+// wider rows give each lane CH float4 chunks).  A worker walks its CSR row four
+// edges at a time: the four neighbour-row loads are issued back to back (each
+// wave-instruction is a fully coalesced 16 B/lane row read), then reduced in
+// registers in CSR order, so the result is deterministic.  Neighbour rows of the
+// block-diagonal molecular graph lie within a few KB of the row itself and are
+// served by L1/L2; HBM sees every x row once and every y row once.
+//
+// Edge weight "modes" share the skeleton:
+//   SUM : w_e (or 1), self term self_coef        (GINConv / scatter_add)
+//   GCN : dis_i w_e dis_j, self dis_i^2           (GCNConv)
+//   GAT : exp(lrelu(sd_i + ss_j) - mx_g)/(den_g+1e-16), appended self loop (GATConv)
+//   RELU: acc += relu(p_i + q_j)                  (restructured GMN message)
+#include "common.hpp"
+
+namespace blgnn {
+
+enum { MODE_SUM = 0, MODE_GCN = 1, MODE_GAT = 2, MODE_RELU = 3 };
+
+struct GatherArgs {
+    const int32_t *rowptr;
+    const int32_t *col;
+    const float *x;      // gathered matrix (h for GCN/GAT, q for RELU)
+    int64_t ldx;
+    float *y;
+    int64_t ldy;
+    int32_t n, d;
+    // SUM / GCN
+    const float *w;      // per-edge weight, nullable
+    float self_coef;
+    int32_t skip_self;
+    const float *dis;    // GCN
+    // GAT
+    const float *s_dst, *s_src, *mx, *den;
+    int32_t group;
+    float slope;
+    // RELU
+    const float *p;
+    int64_t ldp;
+    // epilogue
+    Epilogue epi;
+    int32_t accumulate;
+};
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : slope * v; }
+
+template <int MODE>
+struct EdgeCtx {
+    float a, b, c;   // per-row cached scalars
+    __device__ __forceinline__ void init(const GatherArgs &A, int row) {
+        if (MODE == MODE_GCN) a = A.dis[row];
+        if (MODE == MODE_GAT) {
+            a = A.s_dst[row];
+            if (A.group == BLGNN_GAT_GROUP_DST) { b = A.mx[row]; c = 1.f / (A.den[row] + 1e-16f); }
+        }
+    }
+    // weight of the explicit self term
+    __device__ __forceinline__ float self_w(const GatherArgs &A, int row) const {
+        if (MODE == MODE_SUM) return A.self_coef;
+        if (MODE == MODE_GCN) return a * a;
+        if (MODE == MODE_GAT) {
+            float e = lrelu(a + A.s_src[row], A.slope);
+            return __expf(e - A.mx[row]) / (A.den[row] + 1e-16f);
+        }
+        return 0.f;
+    }
+    // weight of edge e = (j -> row); returns 0 for dropped self loops
+    __device__ __forceinline__ float edge_w(const GatherArgs &A, int row, int j, int e) const {
+        if (MODE == MODE_SUM) {
+            if (A.skip_self && j == row) return 0.f;
+            return A.w ? A.w[e] : 1.f;
+        }
+        if (MODE == MODE_GCN) {
+            if (j == row) return 0.f;
+            return a * (A.w ? A.w[e] : 1.f) * A.dis[j];
+        }
+        if (MODE == MODE_GAT) {
+            if (j == row) return 0.f;
+            float ev = lrelu(a + A.s_src[j], A.slope);
+            if (A.group == BLGNN_GAT_GROUP_DST) return __expf(ev - b) * c;
+            return __expf(ev - A.mx[j]) / (A.den[j] + 1e-16f);
+        }
+        return 1.f;
+    }
+};
+
+template <int MODE, int LG, int CH>
+__global__ void __launch_bounds__(256) k_gather(const GatherArgs A) {
+    constexpr int RPW = WAVE / LG;                       // rows per wave
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int sub = lane / LG, l = lane % LG;
+    const int d4 = A.d >> 2;
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int wave_total = (gridDim.x * blockDim.x) / WAVE;
+    const float4 *__restrict__ X = reinterpret_cast<const float4 *>(A.x);
+    const int64_t ldx4 = A.ldx >> 2, ldy4 = A.ldy >> 2, ldp4 = A.ldp >> 2;
+
+    for (int row = wave_global * RPW + sub; row < A.n; row += wave_total * RPW) {
+        EdgeCtx<MODE> ctx;
+        ctx.init(A, row);
+        float4 acc[CH], prow[CH];
+        bool ok[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            ok[k] = (l + k * LG) < d4;
+            acc[k] = f4_zero();
+            prow[k] = f4_zero();
+        }
+        if (MODE == MODE_RELU) {
+            const float4 *P = reinterpret_cast<const float4 *>(A.p) + (int64_t)row * ldp4;
+#pragma unroll
+            for (int k = 0; k < CH; ++k) if (ok[k]) prow[k] = P[l + k * LG];
+        } else {
+            const float sw = ctx.self_w(A, row);
+            if (sw != 0.f) {
+                const float4 *S = X + (int64_t)row * ldx4;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) if (ok[k]) { float4 v = S[l + k * LG]; f4_fma(acc[k], sw, v); }
+            }
+        }
+        const int e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
+        for (int e = e0; e < e1; e += 4) {
+            int j[4];
+            float w[4];
+            float4 v[4][CH];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = (e + u) < e1;
+                j[u] = in ? A.col[e + u] : row;
+                w[u] = in ? ctx.edge_w(A, row, j[u], e + u) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (w[u] != 0.f) {
+                    const float4 *R = X + (int64_t)j[u] * ldx4;
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) if (ok[k]) v[u][k] = R[l + k * LG];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (w[u] != 0.f) {
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        if (!ok[k]) continue;
+                        if (MODE == MODE_RELU) {
+                            acc[k].x += fmaxf(prow[k].x + v[u][k].x, 0.f);
+                            acc[k].y += fmaxf(prow[k].y + v[u][k].y, 0.f);
+                            acc[k].z += fmaxf(prow[k].z + v[u][k].z, 0.f);
+                            acc[k].w += fmaxf(prow[k].w + v[u][k].w, 0.f);
+                        } else if (MODE == MODE_SUM) {
+                            if (A.w) f4_fma(acc[k], w[u], v[u][k]); else f4_add(acc[k], v[u][k]);
+                        } else {
+                            f4_fma(acc[k], w[u], v[u][k]);
+                        }
+                    }
+                }
+            }
+        }
+        float4 *Y = reinterpret_cast<float4 *>(A.y) + (int64_t)row * ldy4;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (!ok[k]) continue;
+            const int c4 = l + k * LG, c = c4 * 4;
+            float4 r = acc[k];
+            if (MODE == MODE_GCN || MODE == MODE_GAT) {
+                float4 o = A.accumulate ? Y[c4] : f4_zero();
+                const Epilogue &E = A.epi;
+                float t[4] = {r.x, r.y, r.z, r.w};
+                float oo[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float val = t[q] + (E.bias ? E.bias[c + q] : 0.f) + oo[q];
+                    float sl = (E.act == BLGNN_ACT_PRELU && E.act_param) ? E.act_param[c + q] : 0.f;
+                    val = apply_act(val, E.act, sl);
+                    if (E.bn_scale) val = fmaf(val, E.bn_scale[c + q], E.bn_shift ? E.bn_shift[c + q] : 0.f);
+                    t[q] = val;
+                }
+                r = make_float4(t[0], t[1], t[2], t[3]);
+            }
+            Y[c4] = r;
+        }
+    }
+}
+
+// scalar fallback for rows whose width / leading dimension / base pointer is not
+// float4-compatible: one wave per row, channel-outer loop.  Correctness path.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_gather_scalar(const GatherArgs A) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int wave_total = (gridDim.x * blockDim.x) / WAVE;
+    for (int row = wave_global; row < A.n; row += wave_total) {
+        EdgeCtx<MODE> ctx;
+        ctx.init(A, row);
+        const int e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
+        for (int c = lane; c < A.d; c += WAVE) {
+            float acc = 0.f, pr = 0.f;
+            if (MODE == MODE_RELU) pr = A.p[(int64_t)row * A.ldp + c];
+            else {
+                float sw = ctx.self_w(A, row);
+                if (sw != 0.f) acc = sw * A.x[(int64_t)row * A.ldx + c];
+            }
+            for (int e = e0; e < e1; ++e) {
+                int j = A.col[e];
+                float w = ctx.edge_w(A, row, j, e);
+                if (w == 0.f) continue;
+                float v = A.x[(int64_t)j * A.ldx + c];
+                if (MODE == MODE_RELU) acc += fmaxf(pr + v, 0.f);
+                else if (MODE == MODE_SUM && !A.w) acc += v;
+                else acc = fmaf(w, v, acc);
+            }
+            float *yp = A.y + (int64_t)row * A.ldy + c;
+            if (MODE == MODE_GCN || MODE == MODE_GAT) {
+                float val = acc + (A.epi.bias ? A.epi.bias[c] : 0.f) + (A.accumulate ? *yp : 0.f);
+                float sl = (A.epi.act == BLGNN_ACT_PRELU && A.epi.act_param) ? A.epi.act_param[c] : 0.f;
+                val = apply_act(val, A.epi.act, sl);
+                if (A.epi.bn_scale) val = fmaf(val, A.epi.bn_scale[c], A.epi.bn_shift ? A.epi.bn_shift[c] : 0.f);
+                acc = val;
+            }
+            *yp = acc;
+        }
+    }
+}
+
+template <int MODE, int LG, int CH>
+static void launch_vec(const GatherArgs &A, hipStream_t s) {
+    constexpr int RPW = WAVE / LG;
+    const int64_t waves = ((int64_t)A.n + RPW - 1) / RPW;
+    int64_t blocks = (waves + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;   // grid-stride beyond 16 blocks per CU
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((k_gather<MODE, LG, CH>), dim3((unsigned)blocks), dim3(256), 0, s, A);
+}
+
+template <int MODE>
+static int dispatch(const GatherArgs &A, bool extra_aligned, hipStream_t s, const char *what) {
+    if (A.n == 0 || A.d == 0) return BLGNN_OK;
+    const bool vec = (A.d % 4 == 0) && (A.ldx % 4 == 0) && (A.ldy % 4 == 0) &&
+                     aligned16(A.x) && aligned16(A.y) && extra_aligned;
+    const int d4 = A.d / 4;
+    if (vec && d4 <= 512) {
+        if (d4 <= 16) launch_vec<MODE, 16, 1>(A, s);
+        else if (d4 <= 32) launch_vec<MODE, 32, 1>(A, s);
+        else if (d4 <= 64) launch_vec<MODE, 64, 1>(A, s);
+        else if (d4 <= 128) launch_vec<MODE, 64, 2>(A, s);
+        else if (d4 <= 192) launch_vec<MODE, 64, 3>(A, s);
+        else if (d4 <= 256) launch_vec<MODE, 64, 4>(A, s);
+        else if (d4 <= 320) launch_vec<MODE, 64, 5>(A, s);
+        else launch_vec<MODE, 64, 8>(A, s);
+    } else {
+        int64_t blocks = ((int64_t)A.n + 3) / 4;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL((k_gather_scalar<MODE>), dim3((unsigned)blocks), dim3(256), 0, s, A);
+    }
+    return launch_status(what);
+}
+
+// ---- GCN degree ---------------------------------------------------------------
+__global__ void k_gcn_dis(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                          const float *__restrict__ w, int32_t n, float *__restrict__ dis) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float deg = 1.f;                                   // appended self loop, weight 1
+    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e)
+        if (col[e] != i) deg += w ? w[e] : 1.f;
+    float r = 1.f / sqrtf(deg);
+    dis[i] = isinf(r) ? 0.f : r;
+}
+
+__global__ void k_row_degree(const int32_t *__restrict__ rowptr, int32_t n, float *__restrict__ deg) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) deg[i] = (float)(rowptr[i + 1] - rowptr[i]);
+}
+
+// ---- GAT scores: 16 lanes per row ---------------------------------------------
+__global__ void __launch_bounds__(256)
+k_gat_scores(const float *__restrict__ h, int64_t ldh, const float *__restrict__ att, int32_t n,
+             int32_t d, float *__restrict__ s_dst, float *__restrict__ s_src) {
+    constexpr int LG = 16;
+    const int lane = threadIdx.x & (WAVE - 1), l = lane % LG;
+    const int row0 = (blockIdx.x * blockDim.x + threadIdx.x) / LG;
+    const int step = gridDim.x * blockDim.x / LG;
+    for (int row = row0; row < n; row += step) {
+        const float *hr = h + (int64_t)row * ldh;
+        float a = 0.f, b = 0.f;
+        for (int c = l; c < d; c += LG) {
+            float v = hr[c];
+            a = fmaf(v, att[c], a);
+            b = fmaf(v, att[d + c], b);
+        }
+        a = group_sum(a, LG);
+        b = group_sum(b, LG);
+        if (l == 0) { s_dst[row] = a; s_src[row] = b; }
+    }
+}
+
+// ---- GAT softmax statistics: 16 lanes per group node ----------------------------
+__global__ void __launch_bounds__(256)
+k_gat_stats(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+            const float *__restrict__ s_dst, const float *__restrict__ s_src, int32_t n,
+            int32_t group, float slope, float *__restrict__ mx, float *__restrict__ den) {
+    constexpr int LG = 16;
+    const int l = threadIdx.x % LG;
+    const int g0 = (blockIdx.x * blockDim.x + threadIdx.x) / LG;
+    const int step = gridDim.x * blockDim.x / LG;
+    for (int g = g0; g < n; g += step) {
+        const int e0 = rowptr[g], e1 = rowptr[g + 1];
+        const float sd = s_dst[g], ss = s_src[g];
+        const float self_a = lrelu(sd + ss, slope);
+        float m = self_a;
+        for (int e = e0 + l; e < e1; e += LG) {
+            int k = col[e];
+            if (k == g) continue;
+            float a = group == BLGNN_GAT_GROUP_DST ? lrelu(sd + s_src[k], slope)
+                                                   : lrelu(s_dst[k] + ss, slope);
+            m = fmaxf(m, a);
+        }
+        m = group_max(m, LG);
+        float sum = (l == 0) ? __expf(self_a - m) : 0.f;
+        for (int e = e0 + l; e < e1; e += LG) {
+            int k = col[e];
+            if (k == g) continue;
+            float a = group == BLGNN_GAT_GROUP_DST ? lrelu(sd + s_src[k], slope)
+                                                   : lrelu(s_dst[k] + ss, slope);
+            sum += __expf(a - m);
+        }
+        sum = group_sum(sum, LG);
+        if (l == 0) { mx[g] = m; den[g] = sum; }
+    }
+}
+
+}  // namespace blgnn
+
+using namespace blgnn;
+
+static int check_csr(const int32_t *rowptr, const int32_t *col, int32_t n, const char *what) {
+    if (n < 0) return fail(BLGNN_ERR_ARG, "%s: n < 0", what);
+    if (n > 0 && (!rowptr || !col)) return fail(BLGNN_ERR_ARG, "%s: null CSR", what);
+    return BLGNN_OK;
+}
+
+static int grid1d(int64_t items, int per_block) {
+    int64_t b = (items + per_block - 1) / per_block;
+    if (b > 256 * 32) b = 256 * 32;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int blgnn_spmm_sum(const int32_t *rowptr, const int32_t *col, const float *w,
+                              const float *x, int64_t ldx, float *y, int64_t ldy, int32_t n,
+                              int32_t d, float self_coef, int32_t skip_self, void *stream) {
+    if (int rc = check_csr(rowptr, col, n, "spmm_sum")) return rc;
+    BLGNN_CHECK_ARG(d >= 0 && (n == 0 || d == 0 || (x && y)), "spmm_sum: null x/y");
+    BLGNN_CHECK_ARG(ldx >= d && ldy >= d, "spmm_sum: leading dimension < d");
+    BLGNN_CHECK_ARG(x != y, "spmm_sum: x and y must not alias");
+    GatherArgs A = {};
+    A.rowptr = rowptr; A.col = col; A.x = x; A.ldx = ldx; A.y = y; A.ldy = ldy; A.n = n; A.d = d;
+    A.w = w; A.self_coef = self_coef; A.skip_self = skip_self;
+    return dispatch<MODE_SUM>(A, true, (hipStream_t)stream, "spmm_sum");
+}
+
+extern "C" int blgnn_gcn_deg_inv_sqrt(const int32_t *rowptr, const int32_t *col, const float *w,
+                                      int32_t n, float *dis, void *stream) {
+    if (int rc = check_csr(rowptr, col, n, "gcn_deg_inv_sqrt")) return rc;
+    BLGNN_CHECK_ARG(n == 0 || dis, "gcn_deg_inv_sqrt: null dis");
+    if (n == 0) return BLGNN_OK;
+    hipLaunchKernelGGL(k_gcn_dis, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       rowptr, col, w, n, dis);
+    return launch_status("gcn_deg_inv_sqrt");
+}
+
+extern "C" int blgnn_row_degree(const int32_t *rowptr, int32_t n, float *deg, void *stream) {
+    BLGNN_CHECK_ARG(n >= 0 && (n == 0 || (rowptr && deg)), "row_degree: bad args");
+    if (n == 0) return BLGNN_OK;
+    hipLaunchKernelGGL(k_row_degree, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       rowptr, n, deg);
+    return launch_status("row_degree");
+}
+
+extern "C" int blgnn_gcn_aggregate(const int32_t *rowptr, const int32_t *col, const float *w,
+                                   const float *dis, const float *h, int64_t ldh, float *y,
+                                   int64_t ldy, int32_t n, int32_t d, const float *bias,
+                                   int32_t act, const float *act_param, const float *bn_scale,
+                                   const float *bn_shift, void *stream) {
+    if (int rc = check_csr(rowptr, col, n, "gcn_aggregate")) return rc;
+    BLGNN_CHECK_ARG(d >= 0 && (n == 0 || d == 0 || (h && y && dis)), "gcn_aggregate: null pointer");
+    BLGNN_CHECK_ARG(ldh >= d && ldy >= d, "gcn_aggregate: leading dimension < d");
+    BLGNN_CHECK_ARG(h != y, "gcn_aggregate: h and y must not alias");
+    BLGNN_CHECK_ARG(act >= 0 && act <= BLGNN_ACT_TANH, "gcn_aggregate: bad activation id");
+    GatherArgs A = {};
+    A.rowptr = rowptr; A.col = col; A.x = h; A.ldx = ldh; A.y = y; A.ldy = ldy; A.n = n; A.d = d;
+    A.w = w; A.dis = dis;
+    A.epi = Epilogue{bias, act_param, bn_scale, bn_shift, act};
+    return dispatch<MODE_GCN>(A, true, (hipStream_t)stream, "gcn_aggregate");
+}
+
+extern "C" int blgnn_gat_scores(const float *h, int64_t ldh, const float *att, int32_t n,
+                                int32_t d, float *s_dst, float *s_src, void *stream) {
+    BLGNN_CHECK_ARG(n >= 0 && d > 0 && ldh >= d, "gat_scores: bad sizes");
+    BLGNN_CHECK_ARG(n == 0 || (h && att && s_dst && s_src), "gat_scores: null pointer");
+    if (n == 0) return BLGNN_OK;
+    hipLaunchKernelGGL(k_gat_scores, dim3(grid1d(n, 16)), dim3(256), 0, (hipStream_t)stream, h, ldh,
+                       att, n, d, s_dst, s_src);
+    return launch_status("gat_scores");
+}
+
+extern "C" int blgnn_gat_softmax_stats(const int32_t *rowptr, const int32_t *col,
+                                       const float *s_dst, const float *s_src, int32_t n,
+                                       int32_t group, float slope, float *mx, float *den,
+                                       void *stream) {
+    if (int rc = check_csr(rowptr, col, n, "gat_softmax_stats")) return rc;
+    BLGNN_CHECK_ARG(group == BLGNN_GAT_GROUP_SRC || group == BLGNN_GAT_GROUP_DST,
+                    "gat_softmax_stats: bad group");
+    BLGNN_CHECK_ARG(n == 0 || (s_dst && s_src && mx && den), "gat_softmax_stats: null pointer");
+    if (n == 0) return BLGNN_OK;
+    hipLaunchKernelGGL(k_gat_stats, dim3(grid1d(n, 16)), dim3(256), 0, (hipStream_t)stream, rowptr,
+                       col, s_dst, s_src, n, group, slope, mx, den);
+    return launch_status("gat_softmax_stats");
+}
+
+extern "C" int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col, const float *h,
+                                   int64_t ldh, const float *s_dst, const float *s_src,
+                                   const float *mx, const float *den, int32_t group, float slope,
+                                   float *y, int64_t ldy, int32_t n, int32_t d, const float *bias,
+                                   int32_t act, const float *act_param, const float *bn_scale,
+                                   const float *bn_shift, int32_t accumulate, void *stream) {
+    if (int rc = check_csr(rowptr, col, n, "gat_aggregate")) return rc;
+    BLGNN_CHECK_ARG(group == BLGNN_GAT_GROUP_SRC || group == BLGNN_GAT_GROUP_DST,
+                    "gat_aggregate: bad group");
+    BLGNN_CHECK_ARG(d >= 0 && (n == 0 || d == 0 || (h && y && s_dst && s_src && mx && den)),
+                    "gat_aggregate: null pointer");
+    BLGNN_CHECK_ARG(ldh >= d && ldy >= d, "gat_aggregate: leading dimension < d");
+    BLGNN_CHECK_ARG(h != y, "gat_aggregate: h and y must not alias");
+    BLGNN_CHECK_ARG(act >= 0 && act <= BLGNN_ACT_TANH, "gat_aggregate: bad activation id");
+    GatherArgs A = {};
+    A.rowptr = rowptr; A.col = col; A.x = h; A.ldx = ldh; A.y = y; A.ldy = ldy; A.n = n; A.d = d;
+    A.s_dst = s_dst; A.s_src = s_src; A.mx = mx; A.den = den; A.group = group; A.slope = slope;
+    A.epi = Epilogue{bias, act_param, bn_scale, bn_shift, act};
+    A.accumulate = accumulate;
+    return dispatch<MODE_GAT>(A, true, (hipStream_t)stream, "gat_aggregate");
+}
+
+extern "C" int blgnn_edge_relu_sum(const int32_t *rowptr, const int32_t *col, const float *p,
+                                   int64_t ldp, const float *q, int64_t ldq, float *y,
+                                   int64_t ldy, int32_t n, int32_t d, void *stream) {
+    if (int rc = check_csr(rowptr, col, n, "edge_relu_sum")) return rc;
+    BLGNN_CHECK_ARG(d >= 0 && (n == 0 || d == 0 || (p && q && y)), "edge_relu_sum: null pointer");
+    BLGNN_CHECK_ARG(ldp >= d && ldq >= d && ldy >= d, "edge_relu_sum: leading dimension < d");
+    BLGNN_CHECK_ARG(y != p && y != q, "edge_relu_sum: output must not alias inputs");
+    GatherArgs A = {};
+    A.rowptr = rowptr; A.col = col; A.x = q; A.ldx = ldq; A.y = y; A.ldy = ldy; A.n = n; A.d = d;
+    A.p = p; A.ldp = ldp;
+    const bool pa = (ldp % 4 == 0) && aligned16(p);
+    return dispatch<MODE_RELU>(A, pa, (hipStream_t)stream, "edge_relu_sum");
+}

@@ -1,0 +1,200 @@
+// Dense feature transform on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   Y = epi( X[M,K] @ W[K,N] + bias + rowvec (x) rowvec_w )      epi = act, then affine
+//
+// Exact-f32 MFMA (k-ordered fma chain, one rounding per product): results match a
+// plain fp32 reference to summation-order noise, which the 1e-5 parity bar needs.
+//
+// Structure: 256 threads = 4 wavefronts; block tile BM x BN, K step 32, operands
+// staged through LDS in k-major images (As[k][m], Bs[k][n]) so that every
+// ds_read_b32 of a 32x32x2 fragment is bank-conflict free (lane i -> bank i).  The
+// next K tile is fetched global -> registers while the current one is multiplied.
+// Rows of X are the long dimension (atoms / drugs); W is small and L2 resident.
+#include "common.hpp"
+
+namespace blgnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+
+struct LinearArgs {
+    const float *x; int64_t ldx;
+    const float *w; int64_t ldw;
+    float *y; int64_t ldy;
+    int32_t M, N, K;
+    const float *rowvec, *rowvec_w;
+    Epilogue epi;
+    int vec_a, vec_b;      // float4 loads allowed for X / W
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) k_linear(const LinearArgs A) {
+    constexpr int LDA = BM + 1;            // As[k][m]: +1 dword -> conflict-free transposed stores
+    constexpr int LDB = BN + 4;            // Bs[k][n]: keeps 16 B alignment for b128 stores
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int A_F4 = BM / 32;          // float4 per thread per K tile (X)
+    constexpr int B_F4 = BN / 32;          // float4 per thread per K tile (W)
+    constexpr int B_ROWQ = BN / 4;         // float4 per Bs row
+    constexpr int B_KSTEP = 256 / B_ROWQ;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 wavefronts per workgroup");
+
+    __shared__ float As[BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[A_F4], rb[B_F4];
+    const int a_kq = tid & 7, a_row = tid >> 3;          // X: 8 threads x 16 B per row
+    const int b_nq = tid % B_ROWQ, b_k = tid / B_ROWQ;   // W: B_ROWQ threads per k row
+
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int m = m0 + a_row + 32 * i, k = k0 + 4 * a_kq;
+            float4 v = f4_zero();
+            if (m < A.M) {
+                const float *p = A.x + (int64_t)m * A.ldx + k;
+                if (A.vec_a) { if (k < A.K) v = *reinterpret_cast<const float4 *>(p); }
+                else {
+                    if (k + 0 < A.K) v.x = p[0];
+                    if (k + 1 < A.K) v.y = p[1];
+                    if (k + 2 < A.K) v.z = p[2];
+                    if (k + 3 < A.K) v.w = p[3];
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int k = k0 + b_k + B_KSTEP * i, n = n0 + 4 * b_nq;
+            float4 v = f4_zero();
+            if (k < A.K) {
+                const float *p = A.w + (int64_t)k * A.ldw + n;
+                if (A.vec_b) { if (n < A.N) v = *reinterpret_cast<const float4 *>(p); }
+                else {
+                    if (n + 0 < A.N) v.x = p[0];
+                    if (n + 1 < A.N) v.y = p[1];
+                    if (n + 2 < A.N) v.z = p[2];
+                    if (n + 3 < A.N) v.w = p[3];
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int m = a_row + 32 * i, k = 4 * a_kq;
+            As[(k + 0) * LDA + m] = ra[i].x;
+            As[(k + 1) * LDA + m] = ra[i].y;
+            As[(k + 2) * LDA + m] = ra[i].z;
+            As[(k + 3) * LDA + m] = ra[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int k = b_k + B_KSTEP * i;
+            *reinterpret_cast<float4 *>(&Bs[k * LDB + 4 * b_nq]) = rb[i];
+        }
+    };
+
+    const int KT = (A.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    const int fi = lane & 31, fh = lane >> 5;
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) load_tile((kt + 1) * BK);
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[(ks + fh) * LDA + wm0 + 32 * i + fi];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[(ks + fh) * LDB + wn0 + 32 * j + fi];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < KT) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + 32 * j + fi;
+        if (n >= A.N) continue;
+        const float rw = A.rowvec_w ? A.rowvec_w[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (m >= A.M) continue;
+                float v = acc[i][j][r];
+                if (A.rowvec) v = fmaf(A.rowvec[m], rw, v);
+                A.y[(int64_t)m * A.ldy + n] = A.epi(v, n);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_linear(const LinearArgs &A, hipStream_t s) {
+    dim3 grid((A.M + BM - 1) / BM, (A.N + BN - 1) / BN);
+    hipLaunchKernelGGL((k_linear<BM, BN, WM, WN>), grid, dim3(256), 0, s, A);
+}
+
+}  // namespace blgnn
+
+using namespace blgnn;
+
+extern "C" int blgnn_linear(const float *x, int64_t ldx, const float *w, int64_t ldw, float *y,
+                            int64_t ldy, int32_t M, int32_t N, int32_t K, const float *bias,
+                            const float *rowvec, const float *rowvec_w, int32_t act,
+                            const float *act_param, const float *bn_scale, const float *bn_shift,
+                            void *stream) {
+    BLGNN_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "linear: negative size");
+    if (M == 0 || N == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(y && (K == 0 || (x && w)), "linear: null pointer");
+    BLGNN_CHECK_ARG(ldx >= K && ldw >= N && ldy >= N, "linear: leading dimension too small");
+    BLGNN_CHECK_ARG(act >= 0 && act <= BLGNN_ACT_TANH, "linear: bad activation id");
+    BLGNN_CHECK_ARG((rowvec == nullptr) == (rowvec_w == nullptr), "linear: rowvec and rowvec_w go together");
+    BLGNN_CHECK_ARG(x != y, "linear: x and y must not alias");
+    LinearArgs A;
+    A.x = x; A.ldx = ldx; A.w = w; A.ldw = ldw; A.y = y; A.ldy = ldy;
+    A.M = M; A.N = N; A.K = K; A.rowvec = rowvec; A.rowvec_w = rowvec_w;
+    A.epi = Epilogue{bias, act_param, bn_scale, bn_shift, act};
+    A.vec_a = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(x);
+    A.vec_b = (N % 4 == 0) && (ldw % 4 == 0) && aligned16(w);
+    hipStream_t s = (hipStream_t)stream;
+    if (N <= 32) {
+        if (M >= 32768) launch_linear<256, 32, 64, 32>(A, s);
+        else launch_linear<128, 32, 32, 32>(A, s);
+    } else if (N <= 64) {
+        if (M >= 16384) launch_linear<128, 64, 32, 64>(A, s);
+        else launch_linear<64, 64, 32, 32>(A, s);
+    } else {
+        const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+        if (tiles >= 256) launch_linear<128, 128, 64, 64>(A, s);
+        else launch_linear<64, 64, 32, 32>(A, s);
+    }
+    return launch_status("linear");
+}

@@ -1,0 +1,196 @@
+/*
+ * blgnn.h -- C ABI of libblgnn.so: the MI355X (gfx950) bi-level message-passing
+ * hot path.  This is the drop-in boundary.
+ *
+ * The reference (codeKgu/BiLevel-Graph-Neural-Network) is pure Python and has no
+ * FFI of its own; what it binds for this path are the calls it makes into
+ * torch-geometric 1.1.2 / torch-scatter 1.1.2 / torch-sparse 0.2.4 and stock
+ * torch.  Each entry point below names the reference call site(s) it replaces
+ * (path:line under /root/reference).  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *     the name ends in _host.  The caller owns every buffer (outputs are
+ *     pre-allocated); the library never allocates, frees or synchronises.
+ *   - feature matrices are row-major fp32 with an explicit leading dimension
+ *     (ld*, in floats) so that a result can be written straight into a column
+ *     slice of a wider buffer (multi-scale concat, GMN f_node input).
+ *   - graph structure is CSR with int32 indices: rowptr[n+1], col[nnz]; row =
+ *     aggregation target (edge_index[1] of PyG's source_to_target flow), col =
+ *     the sources.  Graph/segment membership is seg[G+1] (node offsets).
+ *   - `stream` is a hipStream_t passed as void*; NULL = the null stream.  All
+ *     functions are asynchronous with respect to the host and re-entrant per
+ *     stream (no global mutable state except the thread-local error string).
+ *   - return value: 0 = BLGNN_OK, negative = error; blgnn_last_error() returns
+ *     a human-readable description for the calling thread.
+ */
+#ifndef BLGNN_H
+#define BLGNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLGNN_OK             0
+#define BLGNN_ERR_ARG       -1   /* null pointer, bad size, bad alignment, bad enum      */
+#define BLGNN_ERR_DEVICE    -2   /* no HIP device / not a gfx950 device                  */
+#define BLGNN_ERR_LAUNCH    -3   /* hipLaunchKernel / hipMemsetAsync reported an error   */
+#define BLGNN_ERR_UNSUPPORTED -4 /* shape outside what the kernels are written for       */
+
+/* activation ids: model/layers_util.py:60-76 (create_act) */
+#define BLGNN_ACT_IDENTITY 0
+#define BLGNN_ACT_RELU     1
+#define BLGNN_ACT_PRELU    2   /* per-channel slope vector                              */
+#define BLGNN_ACT_SIGMOID  3
+#define BLGNN_ACT_TANH     4
+
+/* segment reduce kinds: model/layers_aggregation.py:16-19 */
+#define BLGNN_REDUCE_SUM  0    /* torch_scatter.scatter_add                              */
+#define BLGNN_REDUCE_MEAN 1    /* torch_scatter.scatter_mean (count clamped to >= 1)     */
+
+/* GAT softmax grouping side */
+#define BLGNN_GAT_GROUP_SRC 0  /* PyG 1.1.x: softmax(alpha, edge_index[0], N)            */
+#define BLGNN_GAT_GROUP_DST 1  /* textbook / PyG >= 1.2                                  */
+
+/* ---- library ---------------------------------------------------------- */
+int         blgnn_version(void);
+const char *blgnn_last_error(void);
+/* number of visible gfx950 devices; 0 on a box without one (never negative) */
+int         blgnn_device_count(void);
+
+/* ---- graph layout ------------------------------------------------------ */
+
+/* COO -> CSR.  Replaces the per-forward index plumbing of PyG's
+ * MessagePassing.propagate (call sites model/layers.py:51-54) and the
+ * per-forward rebuild in model/layers_load_interaction_graph.py:11-20.
+ *   key[e] = aggregation target of edge e, nbr[e] = its source (int64, the
+ *   reference's edge_index rows); n = number of nodes.
+ *   rowptr[n+1], col[nnz]: outputs.  Neighbours of a row come out in
+ *   ascending order (deterministic summation order) for any input order.
+ *   work: int32[n+1] scratch.  */
+int blgnn_csr_from_coo(const int64_t *key, const int64_t *nbr, int64_t nnz,
+                       int32_t n, int32_t *rowptr, int32_t *col,
+                       int32_t *work, void *stream);
+
+/* sorted graph-id-per-node vector (src/merged_graph.py:56-57,82 `batch`) ->
+ * segment offsets seg[G+1]. */
+int blgnn_segments_from_batch(const int64_t *batch, int64_t n, int32_t G,
+                              int32_t *seg, void *stream);
+
+/* ---- sparse aggregation (gather -> wavefront segment-reduce) ----------- */
+
+/* y[i] = self_coef * x[i] + sum_{j in row i, (j != i if skip_self)} w_e * x[j]
+ * GINConv aggregation: model/layers.py:26-31,54 (self_coef = 1+eps, skip_self=1,
+ * w = NULL).  Also torch_scatter.scatter_add over gathered rows
+ * (model/layers_gmn.py:42) with self_coef = 0.  x and y must not alias. */
+int blgnn_spmm_sum(const int32_t *rowptr, const int32_t *col, const float *w,
+                   const float *x, int64_t ldx, float *y, int64_t ldy,
+                   int32_t n, int32_t d, float self_coef, int32_t skip_self,
+                   void *stream);
+
+/* GCNConv: model/layers.py:23,52 (formula documented at
+ * model/layers_meta.py:128-148).  Step 1: dis[i] = (1 + sum_{j!=i} w_ij)^-1/2
+ * (inf -> 0).  */
+int blgnn_gcn_deg_inv_sqrt(const int32_t *rowptr, const int32_t *col,
+                           const float *w, int32_t n, float *dis, void *stream);
+/* Step 2: y[i] = epi( dis_i^2 h_i + sum_{j!=i} dis_i w_ij dis_j h_j + bias ),
+ * epi = activation then optional per-channel affine (eval BatchNorm:
+ * model/layers.py:55-57).  bias/act_param/bn_scale/bn_shift may be NULL. */
+int blgnn_gcn_aggregate(const int32_t *rowptr, const int32_t *col,
+                        const float *w, const float *dis, const float *h,
+                        int64_t ldh, float *y, int64_t ldy, int32_t n, int32_t d,
+                        const float *bias, int32_t act, const float *act_param,
+                        const float *bn_scale, const float *bn_shift,
+                        void *stream);
+
+/* GATConv heads=1: model/layers.py:33,54; model/layers_meta.py:70,78.
+ * Step 1: s_dst[i] = h_i . att[0:d], s_src[i] = h_i . att[d:2d]. */
+int blgnn_gat_scores(const float *h, int64_t ldh, const float *att, int32_t n,
+                     int32_t d, float *s_dst, float *s_src, void *stream);
+/* Step 2: per softmax group g: mx[g] = max_e a_e, den[g] = sum_e exp(a_e - mx[g]),
+ * a_e = leaky_relu(s_dst[target] + s_src[source], slope) over the edges of the
+ * group plus the appended self loop; existing self loops are dropped.
+ * (rowptr,col) must be the CSR keyed by the grouping side; for the symmetric
+ * graphs of this path (model/layers_util.py:133) it is the same CSR either way. */
+int blgnn_gat_softmax_stats(const int32_t *rowptr, const int32_t *col,
+                            const float *s_dst, const float *s_src, int32_t n,
+                            int32_t group, float slope, float *mx, float *den,
+                            void *stream);
+/* Step 3: y[i] (+)= epi( sum_{j in N(i) u {i}} alpha_ij h_j + bias ),
+ * alpha_ij = exp(a_ij - mx[g]) / (den[g] + 1e-16), g = j (SRC) or i (DST).
+ * accumulate != 0 adds into y (NodeModelAggrByEdge: model/layers_meta.py:74-79);
+ * the epilogue (act, then affine) is applied to the value being written. */
+int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col,
+                        const float *h, int64_t ldh, const float *s_dst,
+                        const float *s_src, const float *mx, const float *den,
+                        int32_t group, float slope, float *y, int64_t ldy,
+                        int32_t n, int32_t d, const float *bias, int32_t act,
+                        const float *act_param, const float *bn_scale,
+                        const float *bn_shift, int32_t accumulate, void *stream);
+
+/* GMN message: model/layers_gmn.py:38-42 restructured:
+ * y[i] = sum_{e: key_e = i} relu(p[i] + q[nbr_e])  (self loops kept). */
+int blgnn_edge_relu_sum(const int32_t *rowptr, const int32_t *col,
+                        const float *p, int64_t ldp, const float *q, int64_t ldq,
+                        float *y, int64_t ldy, int32_t n, int32_t d, void *stream);
+/* row degree as float (for the deg_i * b2 term of the restructured message) */
+int blgnn_row_degree(const int32_t *rowptr, int32_t n, float *deg, void *stream);
+
+/* ---- readout ------------------------------------------------------------ */
+
+/* out[row_map ? row_map[g] : g][0:d] = reduce_{i in seg[g]..seg[g+1]} x[i]
+ * torch_scatter.scatter_mean / scatter_add over the sorted `batch` vector:
+ * model/layers_aggregation.py:16-19,32-41; with row_map it also performs the
+ * per-gid init_x row writes of model/layers_aggregation.py:68-74. */
+int blgnn_segment_reduce(const int32_t *seg, int32_t G, const float *x,
+                         int64_t ldx, int32_t d, int32_t kind, float *out,
+                         int64_t ldo, const int32_t *row_map, void *stream);
+
+/* ---- dense feature transform (fp32 MFMA) -------------------------------- */
+
+/* Y = epi(X[M,K] @ W[K,N] + bias) (+ addend),  epi = act then per-channel affine.
+ * Replaces torch.mm / nn.Linear inside GINConv's nn (model/layers.py:27-30),
+ * GATConv/GCNConv's x @ weight, MLP (model/layers_util.py:44-57) and the
+ * post-conv act + eval BatchNorm (model/layers.py:55-57).
+ * W is [K,N] row-major (PyG layout); pass nn.Linear weights transposed.
+ * row_scale (nullable): Y[m,:] = epi(X@W + row_scale[m]*bias2 ...) is NOT
+ * provided; instead `rowvec` (nullable, [M]) and `rowvec_w` (nullable, [N])
+ * add rowvec[m] * rowvec_w[n] before the epilogue (the deg_i * b2 term). */
+int blgnn_linear(const float *x, int64_t ldx, const float *w, int64_t ldw,
+                 float *y, int64_t ldy, int32_t M, int32_t N, int32_t K,
+                 const float *bias, const float *rowvec, const float *rowvec_w,
+                 int32_t act, const float *act_param, const float *bn_scale,
+                 const float *bn_shift, void *stream);
+
+/* ---- GMN cross-graph attention ------------------------------------------ */
+
+/* model/layers_gmn.py:55-84.  Graphs (2k, 2k+1) of seg[] form pair k.
+ * u[i] = x[i] - sum_j softmax_j(cos(x_i, x_j)) x_j, j over the partner graph.
+ * seg has 2*num_pairs+1 entries. */
+int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const float *x,
+                    int64_t ldx, float *u, int64_t ldu, int32_t d, void *stream);
+
+/* ---- pair scorer front end ----------------------------------------------- */
+
+/* out[b] = [ z[ids1[b]] / max(|z[ids1[b]]|, eps) , z[ids2[b]] / max(...) ]
+ * model/layers_link_pred.py:44,56-61 (normalize + row gather + cat). */
+int blgnn_pair_gather_normalize(const float *z, int64_t ldz, const int64_t *ids1,
+                                const int64_t *ids2, int32_t B, int32_t d,
+                                float eps, float *out, int64_t ldo, void *stream);
+
+/* y[i] = x[i] / max(|x[i]|_2, eps): model/layers.py:60-61. */
+int blgnn_l2_normalize_rows(const float *x, int64_t ldx, float *y, int64_t ldy,
+                            int32_t n, int32_t d, float eps, void *stream);
+
+/* dst[row_map[g]] = src[g] (model/layers_aggregation.py:72-74 when the readout
+ * is not a plain segment reduce). */
+int blgnn_scatter_rows(const float *src, int64_t lds, const int32_t *row_map,
+                       float *dst, int64_t ldd, int32_t G, int32_t d, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLGNN_H */

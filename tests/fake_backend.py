@@ -1,0 +1,147 @@
+"""TEST-ONLY stand-in for ``blgnn.ops`` on CPU tensors, built from the oracle.
+
+Purpose: exercise the HOST logic of the drop-in modules (spec parsing, parameter
+naming, layer wiring, column-slice outputs, BatchData / MoleculeStore, the
+distributed sharding) in the GPU-less container and under ``gloo``.  It checks
+plumbing only -- both sides of such a test use oracle arithmetic -- and is never
+importable from the product package (tests/test_abi.py enforces that).  Kernel
+parity is established by the ``-m gpu`` tests, which call libblgnn through the C ABI.
+"""
+
+import numpy as np
+import torch
+
+import oracle
+from blgnn import ops as real_ops
+
+
+class FakeCSR(object):
+    def __init__(self, edge_index, n):
+        self.key, self.nbr = edge_index[0], edge_index[1]
+        self.n, self.nnz = n, edge_index.shape[1]
+        self._deg = None
+
+    @property
+    def edge_index(self):          # messages flow nbr -> key
+        return torch.stack([self.nbr, self.key])
+
+
+def csr_from_edge_index(edge_index, num_nodes, symmetric=True):
+    ei = edge_index if symmetric else torch.stack([edge_index[1], edge_index[0]])
+    return FakeCSR(ei, num_nodes)
+
+
+def segments_from_batch(batch, num_graphs):
+    cnt = torch.bincount(batch, minlength=num_graphs)
+    return torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(cnt, 0)]).to(torch.int32)
+
+
+def _batch_of(seg):
+    sizes = (seg[1:] - seg[:-1]).long()
+    return torch.repeat_interleave(torch.arange(sizes.numel()), sizes), sizes.numel()
+
+
+def _put(out, val):
+    if out is None:
+        return val
+    out.copy_(val)
+    return out
+
+
+def _epi(v, act, act_param, bn_scale, bn_shift):
+    v = oracle.apply_act(v, act, act_param)
+    if bn_scale is not None:
+        v = v * bn_scale + (bn_shift if bn_shift is not None else 0)
+    return v
+
+
+def spmm_sum(csr, x, self_coef=0.0, skip_self=False, w=None, out=None):
+    ei = csr.edge_index
+    keep = (ei[0] != ei[1]) if skip_self else torch.ones(ei.shape[1], dtype=torch.bool)
+    msg = x[ei[0][keep]]
+    if w is not None:
+        msg = msg * w[keep].view(-1, 1)
+    return _put(out, self_coef * x + oracle.scatter_add(msg, ei[1][keep], x.shape[0]))
+
+
+def linear(x, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn_shift=None,
+           rowvec=None, rowvec_w=None, out=None):
+    if act not in real_ops.ACT_IDS:
+        raise ValueError("Unknown activation function {}".format(act))
+    v = x @ w_kn
+    if bias is not None:
+        v = v + bias
+    if rowvec is not None:
+        v = v + rowvec.view(-1, 1) * rowvec_w.view(1, -1)
+    return _put(out, _epi(v, act, act_param, bn_scale, bn_shift))
+
+
+def gat_conv(csr, x, weight, att, bias, group="src", slope=0.2, act="identity", act_param=None,
+             bn_scale=None, bn_shift=None, out=None, accumulate=False):
+    v = oracle.gat_conv(x, csr.edge_index, weight, att, bias, group, slope)
+    if accumulate:
+        v = v + out
+    return _put(out, _epi(v, act, act_param, bn_scale, bn_shift))
+
+
+def gcn_conv(csr, x, weight, bias, edge_weight=None, act="identity", act_param=None,
+             bn_scale=None, bn_shift=None, out=None):
+    v = oracle.gcn_conv(x, csr.edge_index, weight, bias, edge_weight)
+    return _put(out, _epi(v, act, act_param, bn_scale, bn_shift))
+
+
+def segment_reduce(seg, x, kind="mean", out=None, row_map=None):
+    batch, G = _batch_of(seg)
+    f = oracle.scatter_mean if kind == "mean" else oracle.scatter_add
+    v = f(x, batch, G)
+    if out is None:
+        out = torch.empty((G, x.shape[1]))
+    if row_map is not None:
+        out[row_map.long()] = v
+    else:
+        out.copy_(v)
+    return out
+
+
+def gmn_match(seg, x, out=None):
+    s = seg.tolist()
+    return _put(out, oracle.gmn_match(x, [(s[i], s[i + 1]) for i in range(len(s) - 1)]))
+
+
+def edge_relu_sum(csr, p, q, out=None):
+    return _put(out, oracle.scatter_add(torch.relu(p[csr.key] + q[csr.nbr]), csr.key, p.shape[0]))
+
+
+def row_degree(csr):
+    return torch.bincount(csr.key, minlength=csr.n).float()
+
+
+def pair_gather_normalize(z, ids1, ids2, eps=1e-12):
+    zn = oracle.l2_normalize(z, eps)
+    return torch.cat([zn[ids1], zn[ids2]], dim=1)
+
+
+def l2_normalize_rows(x, eps=1e-12, out=None):
+    return _put(out, oracle.l2_normalize(x, eps))
+
+
+def scatter_rows(src, row_map, dst):
+    dst[row_map.long()] = src
+    return dst
+
+
+def require_device(t, name="tensor"):
+    return None
+
+
+NAMES = ["csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear", "gat_conv", "gcn_conv",
+         "segment_reduce", "gmn_match", "edge_relu_sum", "row_degree", "pair_gather_normalize",
+         "l2_normalize_rows", "scatter_rows", "require_device"]
+
+
+def install(monkeypatch):
+    """Patch ``blgnn.ops`` in place for the duration of one test."""
+    import sys
+    mod = sys.modules[__name__]
+    for n in NAMES:
+        monkeypatch.setattr(real_ops, n, getattr(mod, n))

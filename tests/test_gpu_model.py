@@ -1,0 +1,160 @@
+"""GPU parity, module / model level: the drop-in nn.Modules built from the reference's
+spec strings, run through libblgnn, against the oracle's interpreter of the same
+spec strings and state_dict (fp32 max|delta| < 1e-5 with calibrated eval-BN)."""
+
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import blgnn
+import oracle
+from blgnn.forward import bilevel_forward, get_initial_embd, all_molecule_pairs
+from helpers import (TOL, max_err, build, layer_specs, state_dict_cpu, plain_batch, oracle_flags,
+                     calibrate_bn)
+
+pytestmark = pytest.mark.gpu
+
+
+def _pairs(ds, B, seed=0):
+    rng = np.random.default_rng(seed)
+    idx = rng.choice(len(ds.pair_gids), size=min(B, len(ds.pair_gids)), replace=False)
+    return ds.pair_gids[idx]
+
+
+def _oracle_bilevel(model, flags, ds, specs, batch_gids, dtype=torch.float64):
+    """lower sweep over all molecules -> init_x -> higher slice, on the CPU oracle"""
+    of = oracle_flags(flags, ds)
+    k = flags.last_lower_lyr_num
+    allp = all_molecule_pairs(ds.gs_map.keys())
+    lower_b = blgnn.BatchData(allp, ds, is_train=False, ignore_pairs=True)
+    plain = plain_batch(lower_b, ds, torch.float32)
+    sd32 = calibrate_bn(model, specs[:k + 1], plain, of)
+    sd = {n: (v.to(dtype) if v.is_floating_point() else v) for n, v in sd32.items()}
+    plain = plain_batch(lower_b, ds, dtype)
+    oracle.run_layers(specs[:k + 1], sd, plain, of)
+    init_x = plain["init_x"]
+    # higher slice
+    hb = blgnn.BatchData(batch_gids, ds, is_train=False)
+    ids = torch.as_tensor(np.vectorize(ds.gs_map.get)(hb.batch_gids))
+    ph = plain_batch(hb, ds, dtype, init_x=init_x, with_pairs=ids)
+    # calibrate the upper BNs on the oracle's own init_x (fp32 weights)
+    ph32 = plain_batch(hb, ds, torch.float32, init_x=init_x.float(), with_pairs=ids)
+    sd32 = calibrate_bn(model, specs[k + 1:], ph32, of, first=k + 1)
+    sd = {n: (v.to(dtype) if v.is_floating_point() else v) for n, v in sd32.items()}
+    acts = oracle.run_layers(specs[k + 1:], sd, ph, of, first=k + 1)
+    return init_x, acts
+
+
+@pytest.mark.parametrize("lower,upper,d", [("gin", "gat", 64), ("gat", "gat", 64), ("gcn", "gcn", 64),
+                                           ("gin", "gin", 128)])
+def test_bignn_forward(device, lower, upper, d):
+    ds = blgnn.make_synthetic(60, 400, seed=1, device=device)
+    flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type=lower,
+                             higher_level_gnn_type=upper, D_lower=d, D_higher=d, device=device)
+    model, data = build(flags, ds, seed=3)
+    specs = layer_specs(flags)
+    pairs = _pairs(ds, 32)
+    init_ref, acts_ref = _oracle_bilevel(model, flags, ds, specs, pairs)
+    preds, bd = bilevel_forward(model, data, pairs)
+    assert max_err(ds.interaction_combo_nxgraph.init_x, init_ref) < TOL
+    assert max_err(preds, acts_ref[-1]) < TOL
+    # every intermediate activation of the higher slice as well
+    for got, ref in zip(model.acts[1:], acts_ref[1:]):
+        assert max_err(got, ref) < TOL
+
+
+@pytest.mark.parametrize("group", ["src", "dst"])
+def test_decagon_forward(device, group):
+    ds = blgnn.make_synthetic(80, 600, seed=2, device=device)
+    flags = blgnn.make_flags("higher_level_gnn", device=device, gat_softmax_group=group)
+    model, data = build(flags, ds, seed=5)
+    ds.init_interaction_graph_embds(device)
+    specs = layer_specs(flags)
+    pairs = _pairs(ds, 64)
+    bd = blgnn.BatchData(pairs, ds, is_train=False)
+    ids = torch.as_tensor(np.vectorize(ds.gs_map.get)(bd.batch_gids))
+    init_x = ds.interaction_combo_nxgraph.init_x
+    of = oracle_flags(flags, ds)
+    sd32 = calibrate_bn(model, specs, plain_batch(bd, ds, torch.float32, init_x=init_x, with_pairs=ids), of)
+    sd = {n: (v.double() if v.is_floating_point() else v) for n, v in sd32.items()}
+    acts = oracle.run_layers(specs, sd, plain_batch(bd, ds, torch.float64, init_x=init_x, with_pairs=ids), of)
+    model.use_layers = 'all'
+    model.acts = [bd.merge_data['merge'].x]
+    for layer in model.layers[:-1]:
+        model.acts.append(layer(model.acts[-1], bd, model))
+    for got, ref in zip(model.acts[1:], acts[1:]):
+        assert max_err(got, ref) < TOL
+
+
+def test_llgnn_forward(device):
+    ds = blgnn.make_synthetic(50, 300, seed=4, device=device)
+    flags = blgnn.make_flags("lower_level_gnn", lower_level_gnn_type="gin", device=device)
+    model, data = build(flags, ds, seed=7)
+    specs = layer_specs(flags)
+    pairs = _pairs(ds, 24)
+    bd = blgnn.BatchData(pairs, ds, is_train=False)
+    ids = torch.as_tensor(np.vectorize(bd.merge_data['gids_to_batch_ind'].get)(bd.batch_gids))
+    of = oracle_flags(flags, ds)
+    sd32 = calibrate_bn(model, specs, plain_batch(bd, ds, torch.float32, with_pairs=ids), of)
+    sd = {n: (v.double() if v.is_floating_point() else v) for n, v in sd32.items()}
+    acts = oracle.run_layers(specs, sd, plain_batch(bd, ds, torch.float64, with_pairs=ids), of)
+    model.acts = [bd.merge_data['merge'].x]
+    for layer in model.layers[:-1]:
+        model.acts.append(layer(model.acts[-1], bd, model))
+    for got, ref in zip(model.acts[1:], acts[1:]):
+        assert max_err(got, ref) < TOL
+
+
+def test_mhcaddi_gmn_forward(device):
+    ds = blgnn.make_synthetic(40, 200, seed=6, device=device)
+    flags = blgnn.make_flags("lower_level_gmn", lower_level_gnn_type="gin", D_lower=64, device=device)
+    model, data = build(flags, ds, seed=9)
+    specs = layer_specs(flags)
+    pairs = _pairs(ds, 16)
+    bd = blgnn.BatchData(pairs, ds, is_train=False, unique_graphs=False)
+    ids = torch.arange(2 * len(pairs)).reshape(-1, 2)
+    of = oracle_flags(flags, ds)
+    sd32 = calibrate_bn(model, specs, plain_batch(bd, ds, torch.float32, with_pairs=ids), of)
+    sd = {n: (v.double() if v.is_floating_point() else v) for n, v in sd32.items()}
+    acts = oracle.run_layers(specs, sd, plain_batch(bd, ds, torch.float64, with_pairs=ids), of)
+    model.acts = [bd.merge_data['merge'].x]
+    for layer in model.layers[:-1]:
+        model.acts.append(layer(model.acts[-1], bd, model))
+    for got, ref in zip(model.acts[1:], acts[1:]):
+        assert max_err(got, ref) < TOL
+
+
+def test_drugcombo_meta_forward(device):
+    ds = blgnn.make_synthetic(70, 500, seed=8, device=device, num_edge_types=2, name="drugcombo_syn")
+    flags = blgnn.make_flags("lower_level_gnn_higher_level", dataset="drugcombo", lower_level_gnn_type="gin",
+                             device=device)
+    model, data = build(flags, ds, seed=11, num_hyper_edge_feat=3)
+    specs = layer_specs(flags)
+    pairs = _pairs(ds, 32)
+    init_ref, acts_ref = _oracle_bilevel(model, flags, ds, specs, pairs)
+    preds, bd = bilevel_forward(model, data, pairs)
+    assert preds.shape[1] == 3
+    assert max_err(ds.interaction_combo_nxgraph.init_x, init_ref) < TOL
+    for got, ref in zip(model.acts[1:], acts_ref[1:]):
+        assert max_err(got, ref) < TOL
+
+
+def test_block_diagonal_independence_and_permutation(device):
+    """a molecule's lower-level output does not depend on what else is in the batch,
+    and permuting the batch order permutes the pooled rows (size-independent properties,
+    checked at the DrugBank-shape size: 1 326 molecules)."""
+    ds = blgnn.make_synthetic(1326, 3000, seed=10, device=device)
+    flags = blgnn.make_flags("lower_level_gnn", lower_level_gnn_type="gin", D_lower=128, device=device)
+    model, data = build(flags, ds, seed=13)
+    model.use_layers = 'lower_layers'
+    gids = np.asarray(ds.molecules.gids)
+    full = model(blgnn.BatchData(all_molecule_pairs(gids), ds, is_train=False, ignore_pairs=True)).clone()
+    perm = np.random.default_rng(0).permutation(len(gids))
+    pg = gids[perm]
+    permuted = model(blgnn.BatchData(all_molecule_pairs(pg), ds, is_train=False, ignore_pairs=True))
+    assert torch.equal(permuted, full[torch.as_tensor(perm, device=device)])
+    sub = gids[100:140]
+    part = model(blgnn.BatchData(all_molecule_pairs(sub), ds, is_train=False, ignore_pairs=True))
+    assert torch.equal(part, full[100:140])

@@ -1,0 +1,232 @@
+"""GPU parity, op level: every C-ABI entry point against the CPU oracle on the same
+seeded inputs (bit-exact for integer layouts, fp32 max|delta| < 1e-5 for features)."""
+
+import numpy as np
+import pytest
+import torch
+
+import blgnn
+from blgnn import ops
+import oracle
+from helpers import TOL, max_err
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_graph(n, avg_deg, seed, self_loops=False, isolated=0):
+    rng = np.random.default_rng(seed)
+    m = max(int(n * avg_deg / 2), 1)
+    e = rng.integers(0, n - isolated, size=(m, 2))
+    if not self_loops:
+        e = e[e[:, 0] != e[:, 1]]
+    return torch.as_tensor(blgnn.graph.to_undirected_host(e, n))
+
+
+def molecule_graph(num_mols, seed):
+    ds = blgnn.make_synthetic(num_mols, 10, seed=seed, device="cpu")
+    merged = ds.molecules.merge(ds.molecules.gids)
+    return merged["merge"].edge_index, merged["merge"].batch, merged["merge"].x.shape[0]
+
+
+def np_csr(key, nbr, n):
+    order = np.lexsort((nbr, key))
+    key, nbr = key[order], nbr[order]
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rowptr, key + 1, 1)
+    return np.cumsum(rowptr), nbr
+
+
+@pytest.mark.parametrize("n,deg,seed", [(1, 0, 0), (7, 2, 1), (300, 5, 2), (5000, 40, 3), (70000, 3, 4)])
+def test_csr_sorted_symmetric(device, n, deg, seed):
+    ei = rand_graph(n, deg, seed, self_loops=True) if deg else torch.zeros((2, 0), dtype=torch.int64)
+    csr = ops.csr_from_edge_index(ei.to(device), n, symmetric=True)
+    rp, col = np_csr(ei[0].numpy(), ei[1].numpy(), n)
+    assert np.array_equal(csr.rowptr.cpu().numpy(), rp)
+    assert np.array_equal(csr.col.cpu().numpy(), col)
+
+
+@pytest.mark.parametrize("n,m,seed", [(50, 400, 0), (2000, 30000, 1), (300, 40000, 2)])
+def test_csr_unsorted_directed(device, n, m, seed):
+    """arbitrary order, duplicates, non-symmetric, rows longer than one wavefront"""
+    rng = np.random.default_rng(seed)
+    ei = torch.as_tensor(rng.integers(0, n, size=(2, m)))
+    csr = ops.csr_from_edge_index(ei.to(device), n, symmetric=False)
+    rp, col = np_csr(ei[1].numpy(), ei[0].numpy(), n)
+    assert np.array_equal(csr.rowptr.cpu().numpy(), rp)
+    assert np.array_equal(csr.col.cpu().numpy(), col)
+
+
+def test_segments_with_empty_graphs(device):
+    batch = torch.as_tensor([0, 0, 2, 2, 2, 5], dtype=torch.int64)
+    seg = ops.segments_from_batch(batch.to(device), 8).cpu().numpy()
+    assert seg.tolist() == [0, 2, 2, 5, 5, 5, 6, 6, 6]
+    seg = ops.segments_from_batch(torch.zeros(0, dtype=torch.int64, device=device), 3).cpu().numpy()
+    assert seg.tolist() == [0, 0, 0, 0]
+
+
+@pytest.mark.parametrize("d", [52, 40, 64, 128, 256, 320, 512, 1280, 2048, 50, 7])
+def test_spmm_gin_aggregate(device, d):
+    ei, _, n = molecule_graph(40, 5)
+    x = torch.randn(n, d)
+    ref = oracle.scatter_add(x[ei[0]], ei[1], n) + 1.0 * x
+    csr = ops.csr_from_edge_index(ei.to(device), n)
+    got = ops.spmm_sum(csr, x.to(device), self_coef=1.0, skip_self=True)
+    assert max_err(got, ref) < TOL
+
+
+def test_spmm_weighted_selfloops_highdeg(device):
+    n, d = 700, 128
+    ei = rand_graph(n, 60, 7, self_loops=True, isolated=5)
+    w = torch.rand(ei.shape[1])
+    x = torch.randn(n, d)
+    csr = ops.csr_from_edge_index(ei.to(device), n)
+    ref = oracle.scatter_add(x[ei[1]] * w.view(-1, 1), ei[0], n) + 0.5 * x   # keyed by ei[0]
+    got = ops.spmm_sum(csr, x.to(device), self_coef=0.5, skip_self=False, w=w.to(device))
+    assert max_err(got, ref) < TOL
+    # into a column slice of a wider buffer
+    wide = torch.zeros(n, 3 * d, device=device)
+    ops.spmm_sum(csr, x.to(device), self_coef=0.5, skip_self=False, w=w.to(device), out=wide[:, d:2 * d])
+    assert max_err(wide[:, d:2 * d], ref) < TOL and float(wide[:, :d].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (37, 3, 2), (500, 16, 128), (1000, 64, 52), (4096, 128, 128),
+                                   (777, 256, 320), (300, 1, 16), (2048, 2048, 512), (50000, 64, 64),
+                                   (129, 130, 131), (40000, 32, 40)])
+def test_linear_shapes(device, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(K, N, generator=g) / max(K, 1) ** 0.5
+    b = torch.randn(N, generator=g)
+    ref = x.double() @ w.double() + b.double()
+    got = ops.linear(x.to(device), w.to(device), b.to(device))
+    assert max_err(got, ref) < TOL
+
+
+@pytest.mark.parametrize("act", ["identity", "relu", "prelu", "sigmoid", "tanh"])
+def test_linear_epilogue(device, act):
+    M, N, K = 333, 96, 72
+    x, w, b = torch.randn(M, K), torch.randn(K, N) / 8, torch.randn(N)
+    slope, scale, shift = torch.rand(N), torch.rand(N) + 0.5, torch.randn(N)
+    rv, rw = torch.rand(M) * 3, torch.randn(N)
+    ref = x.double() @ w.double() + b.double() + rv.double().view(-1, 1) * rw.double().view(1, -1)
+    ref = oracle.apply_act(ref, act, slope.double()) * scale.double() + shift.double()
+    dv = lambda t: t.to(device)
+    got = ops.linear(dv(x), dv(w), dv(b), act=act, act_param=dv(slope), bn_scale=dv(scale),
+                     bn_shift=dv(shift), rowvec=dv(rv), rowvec_w=dv(rw))
+    assert max_err(got, ref) < TOL
+
+
+@pytest.mark.parametrize("group", ["src", "dst"])
+@pytest.mark.parametrize("din,d", [(52, 64), (320, 64), (128, 128), (30, 50)])
+def test_gat_conv(device, group, din, d):
+    n = 400
+    ei = rand_graph(n, 30, 11, self_loops=True, isolated=3)
+    x = torch.randn(n, din)
+    W = torch.randn(din, d) / din ** 0.5
+    att = torch.randn(1, 1, 2 * d) / d ** 0.5
+    b = torch.randn(d) * 0.1
+    ref = oracle.gat_conv(x.double(), ei, W.double(), att.double(), b.double(), group)
+    csr = ops.csr_from_edge_index(ei.to(device), n)
+    got = ops.gat_conv(csr, x.to(device), W.to(device), att.to(device), b.to(device), group=group)
+    assert max_err(got, ref) < TOL
+
+
+def test_gat_conv_molecules_and_accumulate(device):
+    ei, _, n = molecule_graph(30, 3)
+    d = 64
+    x = torch.randn(n, d)
+    params = [(torch.randn(d, d) / 8, torch.randn(1, 1, 2 * d) / 8, torch.randn(d) * 0.1) for _ in range(2)]
+    eis = [ei, rand_graph(n, 4, 5)]
+    ref = torch.relu(oracle.multi_edge_gat(x.double(), eis, [tuple(t.double() for t in p) for p in params], "src"))
+    out = None
+    for i, (e, (W, a, b)) in enumerate(zip(eis, params)):
+        csr = ops.csr_from_edge_index(e.to(device), n)
+        out = ops.gat_conv(csr, x.to(device), W.to(device), a.to(device), b.to(device), group="src",
+                           act="relu" if i == 1 else "identity", out=out, accumulate=i > 0)
+    assert max_err(out, ref) < TOL
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_gcn_conv(device, weighted):
+    n, din, d = 500, 52, 128
+    ei = rand_graph(n, 12, 13, self_loops=True, isolated=4)
+    x, W, b = torch.randn(n, din), torch.randn(din, d) / 7, torch.randn(d) * 0.1
+    ew = torch.rand(ei.shape[1]) + 0.1 if weighted else None
+    if weighted:   # symmetric weights so that CSR-by-row == CSR-by-col
+        key = torch.minimum(ei[0], ei[1]) * n + torch.maximum(ei[0], ei[1])
+        ew = (key.double() * 0.6180339887).frac().float() + 0.1
+    ref = oracle.gcn_conv(x.double(), ei, W.double(), b.double(), None if ew is None else ew.double())
+    csr = ops.csr_from_edge_index(ei.to(device), n)
+    got = ops.gcn_conv(csr, x.to(device), W.to(device), b.to(device),
+                       None if ew is None else ew.to(device), act="identity")
+    assert max_err(got, ref) < TOL
+
+
+@pytest.mark.parametrize("kind", ["mean", "sum"])
+@pytest.mark.parametrize("d", [64, 256, 50, 1280])
+def test_segment_reduce(device, kind, d):
+    sizes = [3, 0, 1, 40, 457, 0, 2, 17]
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.as_tensor(sizes))
+    x = torch.randn(int(sum(sizes)), d)
+    f = oracle.scatter_mean if kind == "mean" else oracle.scatter_add
+    ref = f(x.double(), batch, len(sizes))
+    seg = ops.segments_from_batch(batch.to(device), len(sizes))
+    got = ops.segment_reduce(seg, x.to(device), kind)
+    assert max_err(got, ref) < TOL
+    # multi-scale style: column slice + row redirection
+    wide = torch.zeros(20, 2 * d + 4, device=device)
+    rows = torch.as_tensor([19, 3, 5, 7, 11, 13, 0, 2], dtype=torch.int32, device=device)
+    ops.segment_reduce(seg, x.to(device), kind, out=wide[:, 4:4 + d], row_map=rows)
+    assert max_err(wide[rows.long(), 4:4 + d], ref) < TOL
+
+
+@pytest.mark.parametrize("d,sizes", [(64, [5, 7, 1, 3, 24, 24]), (256, [40, 38, 2, 70, 64, 65]),
+                                     (512, [30, 31]), (256, [150, 170]), (128, [457, 12])])
+def test_gmn_match(device, d, sizes):
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    ind = [(int(off[i]), int(off[i + 1])) for i in range(len(sizes))]
+    x = torch.randn(int(off[-1]), d)
+    ref = oracle.gmn_match(x.double(), ind)
+    seg = torch.as_tensor(off, dtype=torch.int32, device=device)
+    got = ops.gmn_match(seg, x.to(device))
+    assert max_err(got, ref) < TOL
+
+
+def test_edge_relu_sum_matches_message(device):
+    """restructured GMN message == reference formulation (layers_gmn.py:38-42)"""
+    ei, _, n = molecule_graph(25, 9)
+    D = 64
+    x = torch.randn(n, D)
+    lin = [(torch.randn(2 * D, 2 * D) / 11, torch.randn(2 * D) * 0.1) for _ in range(2)]
+    ref = oracle.gmn_message_sum(x.double(), ei, [(w.double(), b.double()) for w, b in lin])
+    (w1, b1), (w2, b2) = lin
+    wpq = torch.cat([w1[:, :D].t(), w1[:, D:].t()], dim=1).contiguous()
+    bpq = torch.cat([b1, torch.zeros_like(b1)])
+    dv = lambda t: t.to(device)
+    csr = ops.csr_from_edge_index(dv(ei), n)
+    pq = ops.linear(dv(x), dv(wpq), dv(bpq))
+    h = ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:])
+    got = ops.linear(h, dv(w2.t().contiguous()), None, rowvec=ops.row_degree(csr), rowvec_w=dv(b2))
+    assert max_err(got, ref) < TOL
+
+
+def test_pair_gather_and_normalize(device):
+    z = torch.randn(100, 192)
+    z[7] = 0.0
+    ids = torch.randint(0, 100, (257, 2))
+    ids[0, 0] = 7
+    zn = oracle.l2_normalize(z.double())
+    ref = torch.cat([zn[ids[:, 0]], zn[ids[:, 1]]], dim=1)
+    got = ops.pair_gather_normalize(z.to(device), ids[:, 0].contiguous().to(device), ids[:, 1].contiguous().to(device))
+    assert max_err(got, ref) < TOL
+    assert max_err(ops.l2_normalize_rows(z.to(device)), zn) < TOL
+
+
+def test_errors_are_loud(device):
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.randn(4, 4), torch.randn(4, 4))          # CPU tensors: no fallback
+    x = torch.randn(8, 8, device=device)
+    with pytest.raises(ValueError):
+        ops.linear(x, torch.randn(7, 8, device=device))
+    with pytest.raises(ValueError):
+        ops.linear(x, x, act="gelu")
