@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DDI edge-pairs/sec of the bi-level forward on N MI355X.
+
+Workload (BASELINE.json configs[1]): DrugBank-shaped synthetic data -- 1 326 drugs per GPU
+(log-normal molecule sizes, ~28 atoms, F_in = 52), interaction graph with 29 240 train pairs
+per 1 326 drugs, lower GIN x5 (d=128) + multi-scale avg-pool readout + upper GAT x3 +
+LinkPred; 4 096 edge pairs scored per GPU per step.
+
+One step = one complete bi-level forward (src/train.py:75-108 of the reference):
+  lower sweep over this rank's molecules -> readout -> [all-gather of pooled drug
+  embeddings over RCCL when N > 1] -> interaction-level GAT x3 -> pair scores for this
+  rank's 4 096 pairs.  Inputs (features, edge lists, pair ids) are resident in HBM before
+  the timed region; the molecule set and the interaction graph are static, so their CSR
+  layouts are built once (the reference rebuilds both per forward).
+
+Weak scaling: per-GPU work is fixed; value = N * 4096 * steps / max-over-ranks time.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the
+dominant kernel (fp32-MFMA feature transform of the lower level, timed live with HIP events
+on the launch stream) and `cpu_baseline` (the CPU oracle on the host cores, bounded sample).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "bilevel-graph-neural-network_amd"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+DRUGS_PER_GPU = 1326
+PAIRS_PER_DRUGSET = 29240      # 70 % train split of DrugBank's 41 772 pairs
+BATCH_PAIRS = 4096
+D = 128
+SEED = 20200614 + 2
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the d=256 SpMM/readout micro-roofline")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+class KernelTimer(object):
+    """HIP-event timing of one op's launches on the stream they are launched on
+    (torch's current stream == the stream handed to libblgnn)."""
+
+    def __init__(self):
+        self.pairs, self.work, self.enabled = [], [], False
+
+    def wrap(self, fn, work_of, select):
+        def wrapped(*a, **k):
+            if not self.enabled or not select(*a, **k):
+                return fn(*a, **k)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            self.pairs.append((e0, e1))
+            self.work.append(work_of(*a, **k))
+            return out
+        return wrapped
+
+    def result(self):
+        ms = [a.elapsed_time(b) for a, b in self.pairs]
+        return ms, self.work
+
+
+def build_workload(rank, world, device):
+    import blgnn
+    from blgnn.dist import ShardedLower
+    n_drugs = DRUGS_PER_GPU * world
+    ds = blgnn.make_synthetic(n_drugs, PAIRS_PER_DRUGSET * world, shape="drugbank", seed=SEED, device=device)
+    flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin",
+                             higher_level_gnn_type="gat", D_lower=D, D_higher=D, device=device,
+                             batch_size=BATCH_PAIRS)
+    blgnn.set_flags(flags)
+    torch.manual_seed(SEED)
+    data = blgnn.TrainData(ds, device=device)
+    ds.init_interaction_graph_feats(flags.init_embds, device, flags.d_init)
+    model = blgnn.Model(data)
+    g = torch.Generator().manual_seed(SEED + 1)
+    with torch.no_grad():                      # eval BN, running stats perturbed by U(-0.1, 0.1)
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.copy_(0.2 * (torch.rand(mod.running_mean.shape, generator=g) - 0.5))
+                mod.running_var.copy_(1.0 + 0.2 * (torch.rand(mod.running_var.shape, generator=g) - 0.5))
+    model.to(device).eval()
+    sharded = ShardedLower(ds.molecules.gids, ds.molecules.sizes, rank, world)
+    return ds, flags, data, model, sharded
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device(device))
+
+    import blgnn
+    from blgnn import ops
+    from blgnn.batch import BatchData
+    from blgnn.forward import all_molecule_pairs
+
+    ds, flags, data, model, sharded = build_workload(rank, world, device)
+    k = flags.last_lower_lyr_num
+    lower_layers = list(model.layers[:k + 1])
+    upper_layers = list(model.layers[k + 1:-1])          # LoadInteraction, GAT x3, LinkPred (no Loss)
+
+    # -- static inputs, resident in HBM before timing -------------------------------------
+    lower_batch = BatchData(all_molecule_pairs(sharded.local_gids), ds, is_train=False, ignore_pairs=True)
+    lower_batch.merge_data['merge'].csr()
+    graph = ds.interaction_combo_nxgraph
+    d_pool = D * 5
+    graph.init_x = torch.zeros((ds.num_graphs(), d_pool), dtype=torch.float32, device=device)
+    ds.init = True
+    rng = np.random.default_rng(SEED + 17 + rank)
+    n_batches = 8
+    upper_batches = []
+    for _ in range(n_batches):
+        idx = rng.choice(len(ds.pair_gids), size=BATCH_PAIRS, replace=False)
+        b = BatchData(ds.pair_gids[idx], ds, is_train=False)
+        upper_batches.append(b)
+    Nn = int(lower_batch.merge_data['merge'].x.shape[0])
+    nnz = int(lower_batch.merge_data['merge'].edge_index.shape[1])
+
+    timer = KernelTimer()
+    real_linear = ops.linear
+    ops.linear = timer.wrap(real_linear, lambda x, w, *a, **kw: 2.0 * x.shape[0] * w.shape[0] * w.shape[1],
+                            lambda x, w, *a, **kw: x.shape[0] == Nn)
+
+    def step(i):
+        with torch.no_grad():
+            model.acts = [lower_batch.merge_data['merge'].x]
+            for layer in lower_layers:
+                model.acts.append(layer(model.acts[-1], lower_batch, model))
+            pooled = model.acts[-1]
+            if world > 1:
+                sharded.gather_init_x(pooled, out=graph.init_x)
+            b = upper_batches[i % n_batches]
+            model.acts = [b.merge_data['merge'].x]
+            for layer in upper_layers:
+                model.acts.append(layer(model.acts[-1], b, model))
+            return model.acts[-1]
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        preds = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert preds.shape == (BATCH_PAIRS, 1) and bool(torch.isfinite(preds).all())
+
+    ms, work = timer.result()
+    ops.linear = real_linear
+    out = None
+    if rank == 0:
+        value = world * BATCH_PAIRS * args.steps / elapsed
+        tflops = sum(work) / (sum(ms) * 1e-3) / 1e12 if ms else 0.0
+        out = {
+            "metric": "DDI edge-pairs/sec (bi-level forward)",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "DrugBank-shape DDI, lower GIN x5 + upper GAT x3, d=128, "
+                                   "batch=4096 edge pairs per GPU (BASELINE configs[1])",
+                       "drugs_per_gpu": DRUGS_PER_GPU, "atoms_per_gpu": Nn, "mol_edges_per_gpu": nnz,
+                       "interaction_pairs": int(len(ds.pair_gids)), "d": D,
+                       "pairs_per_step_per_gpu": BATCH_PAIRS,
+                       "parallelism": "molecule/pair shards x%d + all-gather(pooled)" % world},
+            "roofline": {"kernel": "k_linear<128,128,64,64> (GIN MLP, fp32 MFMA)", "bound": "mfma",
+                         "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "launches": len(ms), "avg_us": 1e3 * sum(ms) / max(len(ms), 1)},
+        }
+        if not args.no_extra:
+            out["extra"] = micro_roofline(device)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ds, flags, model, lower_batch, upper_batches[0], args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def micro_roofline(device):
+    """North-star kernel evidence: molecular SpMM (GIN aggregation) and segment-mean readout at
+    d=256 on a 12 500-molecule x ~40-atom shard (BASELINE configs[3] per-GPU share), HIP-event
+    timed; algorithmic bytes per SURVEY section 8(d)."""
+    import blgnn
+    from blgnn import ops
+    ds = blgnn.make_synthetic(12500, 10, shape="atoms40", seed=SEED + 100, device=device)
+    m = ds.molecules.merge(ds.molecules.gids)["merge"]
+    n, nnz, G, d = m.x.shape[0], m.edge_index.shape[1], m.num_graphs, 256
+    x = torch.randn(n, d, device=device)
+    csr, seg = m.csr(), m.segments()
+    y = torch.empty_like(x)
+    pooled = torch.empty((G, d), device=device)
+    res = {"shape": {"atoms": n, "mol_edges": nnz, "molecules": G, "d": d}}
+
+    def timeit(fn, reps=30):
+        for _ in range(5):
+            fn()
+        evs = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        t = sorted(a.elapsed_time(b) for a, b in evs)
+        return t[len(t) // 2] * 1e-3
+    t = timeit(lambda: ops.spmm_sum(csr, x, 1.0, True, out=y))
+    b = 4.0 * d * n * 2 + 4.0 * nnz + 4.0 * (n + 1)
+    res["spmm_d256"] = {"bound": "hbm", "achieved": b / t / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                        "frac": b / t / 1e9 / PEAK_HBM_GBPS, "alg_bytes": b, "us": t * 1e6}
+    t = timeit(lambda: ops.segment_reduce(seg, x, "mean", out=pooled))
+    b = 4.0 * d * n + 4.0 * d * G + 4.0 * (G + 1)
+    res["readout_d256"] = {"bound": "hbm", "achieved": b / t / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                           "frac": b / t / 1e9 / PEAK_HBM_GBPS, "alg_bytes": b, "us": t * 1e6}
+    w = torch.randn(d, d, device=device) / 16
+    h = torch.empty_like(x)
+    t = timeit(lambda: ops.linear(x, w, out=h), reps=10)
+    f = 2.0 * n * d * d
+    res["linear_d256"] = {"bound": "mfma", "achieved": f / t / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+                          "unit": "TFLOP/s", "frac": f / t / 1e12 / PEAK_F32_MFMA_TFLOPS, "us": t * 1e6}
+    return res
+
+
+def usable_cores():
+    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota
+    (a 1-GPU box exposes all 256 hardware threads but grants a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(ds, flags, model, lower_batch, upper_batch, seconds):
+    """The CPU oracle (pure PyTorch restatement of the reference path) on the host cores, same
+    workload, same weights; bounded sample of whole steps."""
+    import oracle
+    import helpers
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    specs = helpers.layer_specs(flags)
+    k = flags.last_lower_lyr_num
+    sd = helpers.state_dict_cpu(model)
+    of = helpers.oracle_flags(flags, ds)
+    pl = helpers.plain_batch(lower_batch, ds)
+    ids = torch.as_tensor(np.vectorize(ds.gs_map.get)(upper_batch.batch_gids))
+    ph0 = helpers.plain_batch(upper_batch, ds, with_pairs=ids)     # static graph layouts built once
+    n = 0
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        while True:
+            p = dict(pl)
+            p["init_x"] = None
+            oracle.run_layers(specs[:k + 1], sd, p, of)
+            ph = dict(ph0)
+            ph["init_x"] = p["init_x"]
+            oracle.run_layers(specs[k + 1:], sd, ph, of, first=k + 1)
+            n += 1
+            if time.perf_counter() - t0 > seconds or n >= 200:
+                break
+    dt = time.perf_counter() - t0
+    return {"value": n * BATCH_PAIRS / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d whole steps of the same workload (oracle, torch CPU fp32, %d threads), %.1f s"
+                      % (n, cores, dt)}
+
+
+if __name__ == "__main__":
+    main()

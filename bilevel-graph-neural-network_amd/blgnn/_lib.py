@@ -8,6 +8,15 @@ called without a gfx950 device, this module raises -- there is no CPU fallback.
 import ctypes
 import os
 
+# A process must hold ONE HIP runtime.  PyTorch-ROCm bundles its own libamdhip64; if libblgnn
+# were dlopen()ed first it would bind the system copy and device pointers / streams handed over
+# by torch would be foreign to it (every call then fails with "invalid device pointer").
+# Importing torch first makes the loader resolve libblgnn's libamdhip64 to the one torch holds.
+try:
+    import torch  # noqa: F401
+except ImportError:      # a host without torch (plain C / ctypes caller) uses the system runtime
+    torch = None
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libblgnn.so")
 

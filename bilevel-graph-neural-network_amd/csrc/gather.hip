@@ -63,7 +63,7 @@ struct EdgeCtx {
         if (MODE == MODE_GCN) return a * a;
         if (MODE == MODE_GAT) {
             float e = lrelu(a + A.s_src[row], A.slope);
-            return __expf(e - A.mx[row]) / (A.den[row] + 1e-16f);
+            return expf(e - A.mx[row]) / (A.den[row] + 1e-16f);
         }
         return 0.f;
     }
@@ -80,8 +80,8 @@ struct EdgeCtx {
         if (MODE == MODE_GAT) {
             if (j == row) return 0.f;
             float ev = lrelu(a + A.s_src[j], A.slope);
-            if (A.group == BLGNN_GAT_GROUP_DST) return __expf(ev - b) * c;
-            return __expf(ev - A.mx[j]) / (A.den[j] + 1e-16f);
+            if (A.group == BLGNN_GAT_GROUP_DST) return expf(ev - b) * c;
+            return expf(ev - A.mx[j]) / (A.den[j] + 1e-16f);
         }
         return 1.f;
     }
@@ -320,13 +320,13 @@ k_gat_stats(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
             m = fmaxf(m, a);
         }
         m = group_max(m, LG);
-        float sum = (l == 0) ? __expf(self_a - m) : 0.f;
+        float sum = (l == 0) ? expf(self_a - m) : 0.f;
         for (int e = e0 + l; e < e1; e += LG) {
             int k = col[e];
             if (k == g) continue;
             float a = group == BLGNN_GAT_GROUP_DST ? lrelu(sd + s_src[k], slope)
                                                    : lrelu(s_dst[k] + ss, slope);
-            sum += __expf(a - m);
+            sum += expf(a - m);
         }
         sum = group_sum(sum, LG);
         if (l == 0) { mx[g] = m; den[g] = sum; }

@@ -78,8 +78,8 @@ k_gmn_match(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__r
                     s = dot * inva * (1.f / fmaxf(sqrtf(nbq), 1e-12f));
                 }
                 const float m_new = fmaxf(m_run, group_max(s, WAVE));
-                const float resc = __expf(m_run - m_new);          // 0 on the first chunk
-                const float p = live ? __expf(s - m_new) : 0.f;
+                const float resc = expf(m_run - m_new);          // 0 on the first chunk
+                const float p = live ? expf(s - m_new) : 0.f;
                 l_run = l_run * resc + group_sum(p, WAVE);
                 m_run = m_new;
 #pragma unroll

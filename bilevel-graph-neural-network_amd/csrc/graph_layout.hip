@@ -185,9 +185,10 @@ extern "C" int blgnn_csr_from_coo(const int64_t *key, const int64_t *nbr, int64_
     BLGNN_CHECK_ARG(nnz < (int64_t)0x7fffffff, "csr_from_coo: nnz exceeds int32");
     hipStream_t s = (hipStream_t)stream;
     const int64_t len = (int64_t)n + 1;
-    if (hipMemsetAsync(rowptr, 0, sizeof(int32_t) * len, s) != hipSuccess ||
-        hipMemsetAsync(work + n, 0, sizeof(int32_t), s) != hipSuccess)
-        return fail(BLGNN_ERR_LAUNCH, "csr_from_coo: memset failed");
+    hipError_t me = hipMemsetAsync(rowptr, 0, sizeof(int32_t) * len, s);
+    if (me == hipSuccess) me = hipMemsetAsync(work + n, 0, sizeof(int32_t), s);
+    if (me != hipSuccess)
+        return fail(BLGNN_ERR_LAUNCH, "csr_from_coo: hipMemsetAsync: %s", hipGetErrorString(me));
     if (nnz == 0 || n == 0) return launch_status("csr_from_coo(memset)");
     int32_t *flag = work + n;
     const int eb = (int)((nnz + 255) / 256 < 4096 ? (nnz + 255) / 256 : 4096);

@@ -116,6 +116,16 @@ __global__ void __launch_bounds__(256) k_linear(const LinearArgs A) {
     const int fi = lane & 31, fh = lane >> 5;
     for (int kt = 0; kt < KT; ++kt) {
         if (kt + 1 < KT) load_tile((kt + 1) * BK);
+        // two-level accumulation: a fresh 32-deep fma chain per K tile, added to the running
+        // sum afterwards.  Keeps the chain length at 32 for any K (the error of one long
+        // k-ordered chain grows ~4x faster than a blocked CPU sum at K >= 128).
+        f32x16 part[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 2) {
             float a[TM], b[TN];
@@ -127,8 +137,12 @@ __global__ void __launch_bounds__(256) k_linear(const LinearArgs A) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    part[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], part[i][j], 0, 0, 0);
         }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] += part[i][j];
         __syncthreads();
         if (kt + 1 < KT) {
             store_tile();

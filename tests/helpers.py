@@ -105,6 +105,6 @@ def calibrate_bn(model, specs, plain, oflags, first=0, x0=None):
         bn = model.layers[first + k].bn
         with torch.no_grad():
             bn.running_mean.copy_(pre.mean(0).to(bn.running_mean.device))
-            bn.running_var.copy_(pre.var(0, unbiased=False).clamp_min(1e-3).to(bn.running_var.device))
+            bn.running_var.copy_(pre.var(0, unbiased=False).clamp_min(0.5).to(bn.running_var.device))
         sd = state_dict_cpu(model)
     return sd
