@@ -206,7 +206,7 @@ def main():
                        "interaction_pairs": int(len(ds.pair_gids)), "d": D,
                        "pairs_per_step_per_gpu": BATCH_PAIRS,
                        "parallelism": "molecule/pair shards x%d + all-gather(pooled)" % world},
-            "roofline": {"kernel": "k_linear<128,128,64,64> (GIN MLP, fp32 MFMA)", "bound": "mfma",
+            "roofline": {"kernel": "k_linear<64,128,32,64> (lower-level GIN MLP GEMMs, fp32 MFMA)", "bound": "mfma",
                          "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                          "launches": len(ms), "avg_us": 1e3 * sum(ms) / max(len(ms), 1)},

@@ -114,7 +114,7 @@ def spmm_sum(csr, x, self_coef=0.0, skip_self=False, w=None, out=None):
         raise ValueError("blgnn: x has %d rows, graph has %d nodes" % (n, csr.n))
     y = _out(out, n, d, x)
     yp, ldy = _mat(y, "out")
-    call("blgnn_spmm_sum", csr.rowptr.data_ptr(), csr.col.data_ptr(), _vec(w, "w"), xp, ldx,
+    call("blgnn_spmm_sum", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, _vec(w, "w"), xp, ldx,
          yp, ldy, n, d, float(self_coef), int(bool(skip_self)), _stream())
     return y
 
@@ -149,11 +149,11 @@ def gat_conv(csr, x, weight, att, bias, group="src", slope=0.2, act="identity", 
     attv = att.reshape(-1)
     s = _stream()
     call("blgnn_gat_scores", hp, ldh, _vec(attv, "att", optional=False), n, d, s_dst, s_src, s)
-    call("blgnn_gat_softmax_stats", csr.rowptr.data_ptr(), csr.col.data_ptr(), s_dst, s_src, n,
+    call("blgnn_gat_softmax_stats", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, s_dst, s_src, n,
          GAT_GROUP[group], float(slope), mx, den, s)
     y = _out(out, n, d, h)
     yp, ldy = _mat(y, "out")
-    call("blgnn_gat_aggregate", csr.rowptr.data_ptr(), csr.col.data_ptr(), hp, ldh, s_dst, s_src,
+    call("blgnn_gat_aggregate", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, hp, ldh, s_dst, s_src,
          mx, den, GAT_GROUP[group], float(slope), yp, ldy, n, d, _vec(bias, "bias"), _act(act),
          _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"),
          int(bool(accumulate)), s)
@@ -172,7 +172,7 @@ def gcn_conv(csr, x, weight, bias, edge_weight=None, act="identity", act_param=N
          dis.data_ptr(), s)
     y = _out(out, n, d, h)
     yp, ldy = _mat(y, "out")
-    call("blgnn_gcn_aggregate", csr.rowptr.data_ptr(), csr.col.data_ptr(), wp, dis.data_ptr(), hp,
+    call("blgnn_gcn_aggregate", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, wp, dis.data_ptr(), hp,
          ldh, yp, ldy, n, d, _vec(bias, "bias"), _act(act), _vec(act_param, "act_param"),
          _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), s)
     return y
@@ -213,7 +213,7 @@ def edge_relu_sum(csr, p, q, out=None):
     n, d = p.shape
     y = _out(out, n, d, p)
     yp, ldy = _mat(y, "out")
-    call("blgnn_edge_relu_sum", csr.rowptr.data_ptr(), csr.col.data_ptr(), pp, ldp, qp, ldq, yp,
+    call("blgnn_edge_relu_sum", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, pp, ldp, qp, ldq, yp,
          ldy, n, d, _stream())
     return y
 

@@ -186,6 +186,128 @@ __global__ void __launch_bounds__(256) k_gather(const GatherArgs A) {
     }
 }
 
+// "Wide row" variant for high-degree graphs (the interaction level: mean degree 20-60,
+// maximum in the hundreds).  One 256-thread workgroup per output row: the 4 waves x S =
+// 64/LG lane groups are 4*S edge slots that stride over the row's CSR segment, two edges in
+// flight per slot; partial rows meet by wave shuffles, then in LDS ([4][d]) in a fixed order
+// (deterministic).  A kernel that gives each row to ONE lane group runs as long as its
+// heaviest row: 241 us vs ~20 us for the upper GAT of the DrugBank-shape graph.
+template <int MODE, int LG, int CH>
+__global__ void __launch_bounds__(256) k_gather_wide(const GatherArgs A) {
+    constexpr int S = WAVE / LG;                 // edge slots per wave
+    constexpr int NSLOT = 4 * S;
+    extern __shared__ float4 part4[];            // [4][d4]
+    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+    const int sub = lane / LG, l = lane % LG;
+    const int slot = wid * S + sub;
+    const int d4 = A.d >> 2;
+    const float4 *__restrict__ X = reinterpret_cast<const float4 *>(A.x);
+    const int64_t ldx4 = A.ldx >> 2, ldy4 = A.ldy >> 2, ldp4 = A.ldp >> 2;
+
+    for (int row = blockIdx.x; row < A.n; row += gridDim.x) {
+        EdgeCtx<MODE> ctx;
+        ctx.init(A, row);
+        float4 acc[CH], prow[CH];
+        bool ok[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            ok[k] = (l + k * LG) < d4;
+            acc[k] = f4_zero();
+            prow[k] = f4_zero();
+        }
+        if (MODE == MODE_RELU) {
+            const float4 *P = reinterpret_cast<const float4 *>(A.p) + (int64_t)row * ldp4;
+#pragma unroll
+            for (int k = 0; k < CH; ++k) if (ok[k]) prow[k] = P[l + k * LG];
+        } else if (slot == 0) {
+            const float sw = ctx.self_w(A, row);
+            if (sw != 0.f) {
+                const float4 *Sx = X + (int64_t)row * ldx4;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) if (ok[k]) { float4 v = Sx[l + k * LG]; f4_fma(acc[k], sw, v); }
+            }
+        }
+        const int e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
+        for (int e = e0 + slot; e < e1; e += 2 * NSLOT) {
+            int j[2];
+            float w[2];
+            float4 v[2][CH];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ee = e + u * NSLOT;
+                const bool in = ee < e1;
+                j[u] = in ? A.col[ee] : row;
+                w[u] = in ? ctx.edge_w(A, row, j[u], ee) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (w[u] != 0.f) {
+                    const float4 *R = X + (int64_t)j[u] * ldx4;
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) if (ok[k]) v[u][k] = R[l + k * LG];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (w[u] != 0.f) {
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        if (!ok[k]) continue;
+                        if (MODE == MODE_RELU) {
+                            acc[k].x += fmaxf(prow[k].x + v[u][k].x, 0.f);
+                            acc[k].y += fmaxf(prow[k].y + v[u][k].y, 0.f);
+                            acc[k].z += fmaxf(prow[k].z + v[u][k].z, 0.f);
+                            acc[k].w += fmaxf(prow[k].w + v[u][k].w, 0.f);
+                        } else if (MODE == MODE_SUM && !A.w) {
+                            f4_add(acc[k], v[u][k]);
+                        } else {
+                            f4_fma(acc[k], w[u], v[u][k]);
+                        }
+                    }
+                }
+            }
+        }
+        // slots of one wave -> lane group 0
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+#pragma unroll
+            for (int off = LG; off < WAVE; off <<= 1) {
+                acc[k].x += __shfl_xor(acc[k].x, off, WAVE);
+                acc[k].y += __shfl_xor(acc[k].y, off, WAVE);
+                acc[k].z += __shfl_xor(acc[k].z, off, WAVE);
+                acc[k].w += __shfl_xor(acc[k].w, off, WAVE);
+            }
+        }
+        if (sub == 0) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) if (ok[k]) part4[wid * d4 + l + k * LG] = acc[k];
+        }
+        __syncthreads();
+        float4 *Y = reinterpret_cast<float4 *>(A.y) + (int64_t)row * ldy4;
+        for (int c4 = threadIdx.x; c4 < d4; c4 += blockDim.x) {
+            float4 a = part4[c4], b = part4[d4 + c4], c = part4[2 * d4 + c4], dd = part4[3 * d4 + c4];
+            float t[4] = {(a.x + b.x) + (c.x + dd.x), (a.y + b.y) + (c.y + dd.y),
+                          (a.z + b.z) + (c.z + dd.z), (a.w + b.w) + (c.w + dd.w)};
+            if (MODE == MODE_GCN || MODE == MODE_GAT) {
+                const float4 o = A.accumulate ? Y[c4] : f4_zero();
+                const float oo[4] = {o.x, o.y, o.z, o.w};
+                const Epilogue &E = A.epi;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = 4 * c4 + q;
+                    float val = t[q] + (E.bias ? E.bias[c] : 0.f) + oo[q];
+                    float sl = (E.act == BLGNN_ACT_PRELU && E.act_param) ? E.act_param[c] : 0.f;
+                    val = apply_act(val, E.act, sl);
+                    if (E.bn_scale) val = fmaf(val, E.bn_scale[c], E.bn_shift ? E.bn_shift[c] : 0.f);
+                    t[q] = val;
+                }
+            }
+            Y[c4] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+        __syncthreads();
+    }
+}
+
 // scalar fallback for rows whose width / leading dimension / base pointer is not
 // float4-compatible: one wave per row, channel-outer loop.  Correctness path.
 template <int MODE>
@@ -236,13 +358,31 @@ static void launch_vec(const GatherArgs &A, hipStream_t s) {
     hipLaunchKernelGGL((k_gather<MODE, LG, CH>), dim3((unsigned)blocks), dim3(256), 0, s, A);
 }
 
+template <int MODE, int LG, int CH>
+static void launch_wide(const GatherArgs &A, hipStream_t s) {
+    const int blocks = A.n < 256 * 32 ? A.n : 256 * 32;
+    hipLaunchKernelGGL((k_gather_wide<MODE, LG, CH>), dim3(blocks), dim3(256), (size_t)A.d * 16, s, A);
+}
+
+// rows this heavy on average go one-workgroup-per-row (see k_gather_wide)
+constexpr int64_t WIDE_MEAN_DEGREE = 12;
+
 template <int MODE>
-static int dispatch(const GatherArgs &A, bool extra_aligned, hipStream_t s, const char *what) {
+static int dispatch(const GatherArgs &A, int64_t nnz, bool extra_aligned, hipStream_t s, const char *what) {
     if (A.n == 0 || A.d == 0) return BLGNN_OK;
     const bool vec = (A.d % 4 == 0) && (A.ldx % 4 == 0) && (A.ldy % 4 == 0) &&
                      aligned16(A.x) && aligned16(A.y) && extra_aligned;
     const int d4 = A.d / 4;
-    if (vec && d4 <= 512) {
+    if (vec && d4 <= 512 && nnz >= WIDE_MEAN_DEGREE * (int64_t)A.n) {
+        if (d4 <= 16) launch_wide<MODE, 16, 1>(A, s);
+        else if (d4 <= 32) launch_wide<MODE, 32, 1>(A, s);
+        else if (d4 <= 64) launch_wide<MODE, 64, 1>(A, s);
+        else if (d4 <= 128) launch_wide<MODE, 64, 2>(A, s);
+        else if (d4 <= 192) launch_wide<MODE, 64, 3>(A, s);
+        else if (d4 <= 256) launch_wide<MODE, 64, 4>(A, s);
+        else if (d4 <= 320) launch_wide<MODE, 64, 5>(A, s);
+        else launch_wide<MODE, 64, 8>(A, s);
+    } else if (vec && d4 <= 512) {
         if (d4 <= 16) launch_vec<MODE, 16, 1>(A, s);
         else if (d4 <= 32) launch_vec<MODE, 32, 1>(A, s);
         else if (d4 <= 64) launch_vec<MODE, 64, 1>(A, s);
@@ -299,11 +439,11 @@ k_gat_scores(const float *__restrict__ h, int64_t ldh, const float *__restrict__
 }
 
 // ---- GAT softmax statistics: 16 lanes per group node ----------------------------
+template <int LG>
 __global__ void __launch_bounds__(256)
 k_gat_stats(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
             const float *__restrict__ s_dst, const float *__restrict__ s_src, int32_t n,
             int32_t group, float slope, float *__restrict__ mx, float *__restrict__ den) {
-    constexpr int LG = 16;
     const int l = threadIdx.x % LG;
     const int g0 = (blockIdx.x * blockDim.x + threadIdx.x) / LG;
     const int step = gridDim.x * blockDim.x / LG;
@@ -350,7 +490,7 @@ static int grid1d(int64_t items, int per_block) {
     return (int)b;
 }
 
-extern "C" int blgnn_spmm_sum(const int32_t *rowptr, const int32_t *col, const float *w,
+extern "C" int blgnn_spmm_sum(const int32_t *rowptr, const int32_t *col, int64_t nnz, const float *w,
                               const float *x, int64_t ldx, float *y, int64_t ldy, int32_t n,
                               int32_t d, float self_coef, int32_t skip_self, void *stream) {
     if (int rc = check_csr(rowptr, col, n, "spmm_sum")) return rc;
@@ -360,7 +500,7 @@ extern "C" int blgnn_spmm_sum(const int32_t *rowptr, const int32_t *col, const f
     GatherArgs A = {};
     A.rowptr = rowptr; A.col = col; A.x = x; A.ldx = ldx; A.y = y; A.ldy = ldy; A.n = n; A.d = d;
     A.w = w; A.self_coef = self_coef; A.skip_self = skip_self;
-    return dispatch<MODE_SUM>(A, true, (hipStream_t)stream, "spmm_sum");
+    return dispatch<MODE_SUM>(A, nnz, true, (hipStream_t)stream, "spmm_sum");
 }
 
 extern "C" int blgnn_gcn_deg_inv_sqrt(const int32_t *rowptr, const int32_t *col, const float *w,
@@ -381,7 +521,7 @@ extern "C" int blgnn_row_degree(const int32_t *rowptr, int32_t n, float *deg, vo
     return launch_status("row_degree");
 }
 
-extern "C" int blgnn_gcn_aggregate(const int32_t *rowptr, const int32_t *col, const float *w,
+extern "C" int blgnn_gcn_aggregate(const int32_t *rowptr, const int32_t *col, int64_t nnz, const float *w,
                                    const float *dis, const float *h, int64_t ldh, float *y,
                                    int64_t ldy, int32_t n, int32_t d, const float *bias,
                                    int32_t act, const float *act_param, const float *bn_scale,
@@ -395,7 +535,7 @@ extern "C" int blgnn_gcn_aggregate(const int32_t *rowptr, const int32_t *col, co
     A.rowptr = rowptr; A.col = col; A.x = h; A.ldx = ldh; A.y = y; A.ldy = ldy; A.n = n; A.d = d;
     A.w = w; A.dis = dis;
     A.epi = Epilogue{bias, act_param, bn_scale, bn_shift, act};
-    return dispatch<MODE_GCN>(A, true, (hipStream_t)stream, "gcn_aggregate");
+    return dispatch<MODE_GCN>(A, nnz, true, (hipStream_t)stream, "gcn_aggregate");
 }
 
 extern "C" int blgnn_gat_scores(const float *h, int64_t ldh, const float *att, int32_t n,
@@ -408,7 +548,7 @@ extern "C" int blgnn_gat_scores(const float *h, int64_t ldh, const float *att, i
     return launch_status("gat_scores");
 }
 
-extern "C" int blgnn_gat_softmax_stats(const int32_t *rowptr, const int32_t *col,
+extern "C" int blgnn_gat_softmax_stats(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                                        const float *s_dst, const float *s_src, int32_t n,
                                        int32_t group, float slope, float *mx, float *den,
                                        void *stream) {
@@ -417,12 +557,16 @@ extern "C" int blgnn_gat_softmax_stats(const int32_t *rowptr, const int32_t *col
                     "gat_softmax_stats: bad group");
     BLGNN_CHECK_ARG(n == 0 || (s_dst && s_src && mx && den), "gat_softmax_stats: null pointer");
     if (n == 0) return BLGNN_OK;
-    hipLaunchKernelGGL(k_gat_stats, dim3(grid1d(n, 16)), dim3(256), 0, (hipStream_t)stream, rowptr,
-                       col, s_dst, s_src, n, group, slope, mx, den);
+    if (nnz >= WIDE_MEAN_DEGREE * (int64_t)n)      // high-degree graph: a whole wavefront per node
+        hipLaunchKernelGGL(k_gat_stats<64>, dim3(grid1d(n, 4)), dim3(256), 0, (hipStream_t)stream, rowptr,
+                           col, s_dst, s_src, n, group, slope, mx, den);
+    else
+        hipLaunchKernelGGL(k_gat_stats<16>, dim3(grid1d(n, 16)), dim3(256), 0, (hipStream_t)stream, rowptr,
+                           col, s_dst, s_src, n, group, slope, mx, den);
     return launch_status("gat_softmax_stats");
 }
 
-extern "C" int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col, const float *h,
+extern "C" int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col, int64_t nnz, const float *h,
                                    int64_t ldh, const float *s_dst, const float *s_src,
                                    const float *mx, const float *den, int32_t group, float slope,
                                    float *y, int64_t ldy, int32_t n, int32_t d, const float *bias,
@@ -441,10 +585,10 @@ extern "C" int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col, co
     A.s_dst = s_dst; A.s_src = s_src; A.mx = mx; A.den = den; A.group = group; A.slope = slope;
     A.epi = Epilogue{bias, act_param, bn_scale, bn_shift, act};
     A.accumulate = accumulate;
-    return dispatch<MODE_GAT>(A, true, (hipStream_t)stream, "gat_aggregate");
+    return dispatch<MODE_GAT>(A, nnz, true, (hipStream_t)stream, "gat_aggregate");
 }
 
-extern "C" int blgnn_edge_relu_sum(const int32_t *rowptr, const int32_t *col, const float *p,
+extern "C" int blgnn_edge_relu_sum(const int32_t *rowptr, const int32_t *col, int64_t nnz, const float *p,
                                    int64_t ldp, const float *q, int64_t ldq, float *y,
                                    int64_t ldy, int32_t n, int32_t d, void *stream) {
     if (int rc = check_csr(rowptr, col, n, "edge_relu_sum")) return rc;
@@ -455,5 +599,5 @@ extern "C" int blgnn_edge_relu_sum(const int32_t *rowptr, const int32_t *col, co
     A.rowptr = rowptr; A.col = col; A.x = q; A.ldx = ldq; A.y = y; A.ldy = ldy; A.n = n; A.d = d;
     A.p = p; A.ldp = ldp;
     const bool pa = (ldp % 4 == 0) && aligned16(p);
-    return dispatch<MODE_RELU>(A, pa, (hipStream_t)stream, "edge_relu_sum");
+    return dispatch<MODE_RELU>(A, nnz, pa, (hipStream_t)stream, "edge_relu_sum");
 }

@@ -206,8 +206,12 @@ extern "C" int blgnn_linear(const float *x, int64_t ldx, const float *w, int64_t
         if (M >= 16384) launch_linear<128, 64, 32, 64>(A, s);
         else launch_linear<64, 64, 32, 32>(A, s);
     } else {
+        // 128x128 tiles only when they fill the chip several times over; a grid of 1-2
+        // tiles per CU (36 k atoms x 128) runs in whole "rounds" and loses up to half of one,
+        // so mid-size problems take 64-row tiles that are all resident together.
         const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
-        if (tiles >= 256) launch_linear<128, 128, 64, 64>(A, s);
+        if (tiles >= 1024) launch_linear<128, 128, 64, 64>(A, s);
+        else if (M >= 4096) launch_linear<64, 128, 32, 64>(A, s);
         else launch_linear<64, 64, 32, 32>(A, s);
     }
     return launch_status("linear");

@@ -18,7 +18,9 @@
  *     slice of a wider buffer (multi-scale concat, GMN f_node input).
  *   - graph structure is CSR with int32 indices: rowptr[n+1], col[nnz]; row =
  *     aggregation target (edge_index[1] of PyG's source_to_target flow), col =
- *     the sources.  Graph/segment membership is seg[G+1] (node offsets).
+ *     the sources; nnz = rowptr[n] is passed by the caller (it selects the launch
+ *     shape: per-row-group kernels for molecular graphs, one workgroup per row for
+ *     high-degree interaction graphs).  Graph/segment membership is seg[G+1].
  *   - `stream` is a hipStream_t passed as void*; NULL = the null stream.  All
  *     functions are asynchronous with respect to the host and re-entrant per
  *     stream (no global mutable state except the thread-local error string).
@@ -86,7 +88,7 @@ int blgnn_segments_from_batch(const int64_t *batch, int64_t n, int32_t G,
  * GINConv aggregation: model/layers.py:26-31,54 (self_coef = 1+eps, skip_self=1,
  * w = NULL).  Also torch_scatter.scatter_add over gathered rows
  * (model/layers_gmn.py:42) with self_coef = 0.  x and y must not alias. */
-int blgnn_spmm_sum(const int32_t *rowptr, const int32_t *col, const float *w,
+int blgnn_spmm_sum(const int32_t *rowptr, const int32_t *col, int64_t nnz, const float *w,
                    const float *x, int64_t ldx, float *y, int64_t ldy,
                    int32_t n, int32_t d, float self_coef, int32_t skip_self,
                    void *stream);
@@ -99,7 +101,7 @@ int blgnn_gcn_deg_inv_sqrt(const int32_t *rowptr, const int32_t *col,
 /* Step 2: y[i] = epi( dis_i^2 h_i + sum_{j!=i} dis_i w_ij dis_j h_j + bias ),
  * epi = activation then optional per-channel affine (eval BatchNorm:
  * model/layers.py:55-57).  bias/act_param/bn_scale/bn_shift may be NULL. */
-int blgnn_gcn_aggregate(const int32_t *rowptr, const int32_t *col,
+int blgnn_gcn_aggregate(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                         const float *w, const float *dis, const float *h,
                         int64_t ldh, float *y, int64_t ldy, int32_t n, int32_t d,
                         const float *bias, int32_t act, const float *act_param,
@@ -115,7 +117,7 @@ int blgnn_gat_scores(const float *h, int64_t ldh, const float *att, int32_t n,
  * group plus the appended self loop; existing self loops are dropped.
  * (rowptr,col) must be the CSR keyed by the grouping side; for the symmetric
  * graphs of this path (model/layers_util.py:133) it is the same CSR either way. */
-int blgnn_gat_softmax_stats(const int32_t *rowptr, const int32_t *col,
+int blgnn_gat_softmax_stats(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                             const float *s_dst, const float *s_src, int32_t n,
                             int32_t group, float slope, float *mx, float *den,
                             void *stream);
@@ -123,7 +125,7 @@ int blgnn_gat_softmax_stats(const int32_t *rowptr, const int32_t *col,
  * alpha_ij = exp(a_ij - mx[g]) / (den[g] + 1e-16), g = j (SRC) or i (DST).
  * accumulate != 0 adds into y (NodeModelAggrByEdge: model/layers_meta.py:74-79);
  * the epilogue (act, then affine) is applied to the value being written. */
-int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col,
+int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                         const float *h, int64_t ldh, const float *s_dst,
                         const float *s_src, const float *mx, const float *den,
                         int32_t group, float slope, float *y, int64_t ldy,
@@ -133,7 +135,7 @@ int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col,
 
 /* GMN message: model/layers_gmn.py:38-42 restructured:
  * y[i] = sum_{e: key_e = i} relu(p[i] + q[nbr_e])  (self loops kept). */
-int blgnn_edge_relu_sum(const int32_t *rowptr, const int32_t *col,
+int blgnn_edge_relu_sum(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                         const float *p, int64_t ldp, const float *q, int64_t ldq,
                         float *y, int64_t ldy, int32_t n, int32_t d, void *stream);
 /* row degree as float (for the deg_i * b2 term of the restructured message) */
@@ -156,9 +158,9 @@ int blgnn_segment_reduce(const int32_t *seg, int32_t G, const float *x,
  * GATConv/GCNConv's x @ weight, MLP (model/layers_util.py:44-57) and the
  * post-conv act + eval BatchNorm (model/layers.py:55-57).
  * W is [K,N] row-major (PyG layout); pass nn.Linear weights transposed.
- * row_scale (nullable): Y[m,:] = epi(X@W + row_scale[m]*bias2 ...) is NOT
- * provided; instead `rowvec` (nullable, [M]) and `rowvec_w` (nullable, [N])
- * add rowvec[m] * rowvec_w[n] before the epilogue (the deg_i * b2 term). */
+ * rowvec [M] and rowvec_w [N] (both or neither) add the rank-1 term
+ * rowvec[m] * rowvec_w[n] before the epilogue (the deg_i * b2 term of the
+ * restructured GMN message). */
 int blgnn_linear(const float *x, int64_t ldx, const float *w, int64_t ldw,
                  float *y, int64_t ldy, int32_t M, int32_t N, int32_t K,
                  const float *bias, const float *rowvec, const float *rowvec_w,
