@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the d=256 SpMM/readout micro-roofline")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every kernel eagerly instead of replaying captured HIP graphs")
     return ap.parse_args()
 
 
@@ -147,10 +149,14 @@ def main():
     Nn = int(lower_batch.merge_data['merge'].x.shape[0])
     nnz = int(lower_batch.merge_data['merge'].edge_index.shape[1])
 
+    # dominant kernel: the fused GIN layer (CSR gather -> LDS -> 2 fp32-MFMA GEMMs -> epilogue)
     timer = KernelTimer()
-    real_linear = ops.linear
-    ops.linear = timer.wrap(real_linear, lambda x, w, *a, **kw: 2.0 * x.shape[0] * w.shape[0] * w.shape[1],
-                            lambda x, w, *a, **kw: x.shape[0] == Nn)
+    real_gin = ops.gin_layer
+    ops.gin_layer = timer.wrap(
+        real_gin,
+        lambda csr, x, w1, b1, w2, *a, **kw: (2.0 * x.shape[0] * (w1.shape[0] * w1.shape[1] + w2.shape[0] * w2.shape[1]),
+                                              4.0 * x.shape[0] * (x.shape[1] + w1.shape[1]) + 4.0 * csr.nnz + 4.0 * (csr.n + 1)),
+        lambda *a, **kw: True)
 
     def step(i):
         with torch.no_grad():
@@ -166,22 +172,53 @@ def main():
                 model.acts.append(layer(model.acts[-1], b, model))
             return model.acts[-1]
 
-    for i in range(args.warmup):
+    # The forward is ~45 short launches: captured once per distinct pair batch into a HIP graph
+    # (launch-bound inner loops belong in graphs) and replayed in the timed region.  RCCL
+    # collectives stay outside graphs: with N > 1 the step runs eagerly.
+    use_graph = (not args.no_graph) and world == 1
+    for i in range(max(args.warmup, 3)):
         step(i)
+    torch.cuda.synchronize()
+    graphs, outs = [], []
+    if use_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(n_batches):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    outs.append(step(i))
+                graphs.append(g)
+        torch.cuda.current_stream().wait_stream(side)
+        for i in range(args.warmup):
+            graphs[i % n_batches].replay()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        preds = step(i)
+    if use_graph:
+        for i in range(args.steps):
+            graphs[i % n_batches].replay()
+        preds = outs[(args.steps - 1) % n_batches]
+    else:
+        timer.enabled = True
+        for i in range(args.steps):
+            preds = step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    if use_graph:
+        # HIP events cannot sit inside a replayed graph: the dominant kernel is timed over the
+        # same K steps launched eagerly right after the timed region (same inputs, same stream)
+        timer.enabled = True
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        timer.enabled = False
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -189,11 +226,12 @@ def main():
     assert preds.shape == (BATCH_PAIRS, 1) and bool(torch.isfinite(preds).all())
 
     ms, work = timer.result()
-    ops.linear = real_linear
+    ops.gin_layer = real_gin
     out = None
     if rank == 0:
         value = world * BATCH_PAIRS * args.steps / elapsed
-        tflops = sum(work) / (sum(ms) * 1e-3) / 1e12 if ms else 0.0
+        tflops = sum(w[0] for w in work) / (sum(ms) * 1e-3) / 1e12 if ms else 0.0
+        alg_gbps = sum(w[1] for w in work) / (sum(ms) * 1e-3) / 1e9 if ms else 0.0
         out = {
             "metric": "DDI edge-pairs/sec (bi-level forward)",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
@@ -204,12 +242,13 @@ def main():
                                    "batch=4096 edge pairs per GPU (BASELINE configs[1])",
                        "drugs_per_gpu": DRUGS_PER_GPU, "atoms_per_gpu": Nn, "mol_edges_per_gpu": nnz,
                        "interaction_pairs": int(len(ds.pair_gids)), "d": D,
-                       "pairs_per_step_per_gpu": BATCH_PAIRS,
+                       "pairs_per_step_per_gpu": BATCH_PAIRS, "hip_graph": bool(use_graph),
                        "parallelism": "molecule/pair shards x%d + all-gather(pooled)" % world},
-            "roofline": {"kernel": "k_linear<64,128,32,64> (lower-level GIN MLP GEMMs, fp32 MFMA)", "bound": "mfma",
-                         "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"kernel": "k_gin_layer (fused GIN layer: CSR gather + 2 fp32-MFMA GEMMs + act/BN)",
+                         "bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "launches": len(ms), "avg_us": 1e3 * sum(ms) / max(len(ms), 1)},
+                         "launches": len(ms), "avg_us": 1e3 * sum(ms) / max(len(ms), 1),
+                         "alg_hbm_GBps": alg_gbps, "alg_hbm_frac": alg_gbps / PEAK_HBM_GBPS},
         }
         if not args.no_extra:
             out["extra"] = micro_roofline(device)

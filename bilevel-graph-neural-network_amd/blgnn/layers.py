@@ -107,10 +107,14 @@ class NodeEmbedding(nn.Module):
                 w1 = self._cache.get("w1", lambda w: w.t().contiguous(), lin1.weight)
                 w2 = self._cache.get("w2", lambda w: w.t().contiguous(), lin2.weight)
                 eps = self._cache.get("eps", lambda e: float(e[0]), self.conv.eps)
-                agg = ops.spmm_sum(csr, ins, self_coef=1.0 + eps, skip_self=True)
-                h = ops.linear(agg, w1, lin1.bias, act=act, act_param=slopes)
-                x = ops.linear(h, w2, lin2.bias, act=act, act_param=slopes,
-                               bn_scale=scale, bn_shift=shift, out=out)
+                if ops.gin_layer_supported(csr, ins, ins.shape[1], self.out_dim):
+                    x = ops.gin_layer(csr, ins, w1, lin1.bias, w2, lin2.bias, eps=eps, act=act,
+                                      act_param=slopes, bn_scale=scale, bn_shift=shift, out=out)
+                else:
+                    agg = ops.spmm_sum(csr, ins, self_coef=1.0 + eps, skip_self=True)
+                    h = ops.linear(agg, w1, lin1.bias, act=act, act_param=slopes)
+                    x = ops.linear(h, w2, lin2.bias, act=act, act_param=slopes,
+                                   bn_scale=scale, bn_shift=shift, out=out)
             elif self.type == 'gat':
                 x = ops.gat_conv(csr, ins, self.conv.weight, self.conv.att, self.conv.bias,
                                  group=getattr(FLAGS, "gat_softmax_group", "src"),

@@ -13,7 +13,7 @@ from ._lib import call, ACT_IDS, GAT_GROUP, REDUCE_MEAN, REDUCE_SUM
 __all__ = [
     "CSR", "csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear",
     "gat_conv", "gcn_conv", "segment_reduce", "gmn_match", "edge_relu_sum",
-    "row_degree", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
+    "row_degree", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
     "require_device",
 ]
 
@@ -116,6 +116,33 @@ def spmm_sum(csr, x, self_coef=0.0, skip_self=False, w=None, out=None):
     yp, ldy = _mat(y, "out")
     call("blgnn_spmm_sum", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, _vec(w, "w"), xp, ldx,
          yp, ldy, n, d, float(self_coef), int(bool(skip_self)), _stream())
+    return y
+
+
+def gin_layer_supported(csr, x, K, N):
+    """Shapes the single-launch fused GIN layer is written for (include/blgnn.h), on
+    low-degree (molecular) graphs; high-degree interaction graphs take the one-workgroup-
+    per-row aggregation kernel followed by the two GEMMs."""
+    return (N in (64, 128, 256) and K % 4 == 0 and K <= 256 and x.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0 and csr.nnz < 12 * max(csr.n, 1))
+
+
+def gin_layer(csr, x, w1_kn, b1, w2_kn, b2, eps=0.0, act="identity", act_param=None,
+              bn_scale=None, bn_shift=None, out=None):
+    """Whole GIN NodeEmbedding layer (aggregate -> Linear -> act -> Linear -> act -> BN) in
+    one kernel; the aggregated tile and the hidden activation never leave LDS."""
+    xp, ldx = _mat(x, "x")
+    n, K = x.shape
+    N = w1_kn.shape[1]
+    if w1_kn.shape[0] != K or tuple(w2_kn.shape) != (N, N):
+        raise ValueError("blgnn: gin_layer weight shapes %s / %s do not match x [%d,%d]"
+                         % (tuple(w1_kn.shape), tuple(w2_kn.shape), n, K))
+    y = _out(out, n, N, x)
+    yp, ldy = _mat(y, "out")
+    call("blgnn_gin_layer", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, xp, ldx, n, K,
+         _vec(w1_kn, "w1", optional=False), _vec(b1, "b1"), _vec(w2_kn, "w2", optional=False),
+         _vec(b2, "b2"), N, float(eps), _act(act), _vec(act_param, "act_param"),
+         _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), yp, ldy, _stream())
     return y
 
 

@@ -82,4 +82,26 @@ struct Epilogue {
     }
 };
 
+// The epilogue of ONE output channel with its parameters already in registers.  Kernels whose
+// lanes own a column (the MFMA C/D layout) load this once before their store loop: the
+// compiler cannot hoist the parameter loads itself because the stores may alias them, and
+// four dependent L1 round trips in front of each of 32-64 stores cost more than the GEMM.
+struct EpilogueCol {
+    float bias, slope, scale, shift;
+    int act;
+    bool affine;
+    __device__ __forceinline__ EpilogueCol(const Epilogue &E, int c, bool valid) {
+        bias = (valid && E.bias) ? E.bias[c] : 0.f;
+        slope = (valid && E.act == BLGNN_ACT_PRELU && E.act_param) ? E.act_param[c] : 0.f;
+        affine = E.bn_scale != nullptr;
+        scale = (valid && affine) ? E.bn_scale[c] : 1.f;
+        shift = (valid && affine && E.bn_shift) ? E.bn_shift[c] : 0.f;
+        act = E.act;
+    }
+    __device__ __forceinline__ float operator()(float v) const {
+        v = apply_act(v + bias, act, slope);
+        return affine ? fmaf(v, scale, shift) : v;
+    }
+};
+
 }  // namespace blgnn

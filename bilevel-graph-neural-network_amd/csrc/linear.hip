@@ -156,6 +156,7 @@ __global__ void __launch_bounds__(256) k_linear(const LinearArgs A) {
         const int n = n0 + wn0 + 32 * j + fi;
         if (n >= A.N) continue;
         const float rw = A.rowvec_w ? A.rowvec_w[n] : 0.f;
+        const EpilogueCol epi(A.epi, n, true);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -164,7 +165,7 @@ __global__ void __launch_bounds__(256) k_linear(const LinearArgs A) {
                 if (m >= A.M) continue;
                 float v = acc[i][j][r];
                 if (A.rowvec) v = fmaf(A.rowvec[m], rw, v);
-                A.y[(int64_t)m * A.ldy + n] = A.epi(v, n);
+                A.y[(int64_t)m * A.ldy + n] = epi(v);
             }
         }
     }

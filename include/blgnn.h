@@ -93,6 +93,22 @@ int blgnn_spmm_sum(const int32_t *rowptr, const int32_t *col, int64_t nnz, const
                    int32_t n, int32_t d, float self_coef, int32_t skip_self,
                    void *stream);
 
+/* One whole GIN NodeEmbedding layer in ONE launch: model/layers.py:26-31,51-57.
+ *   y = affine( act( act( agg @ w1 + b1 ) @ w2 + b2 ) ),
+ *   agg_i = (1 + eps) x_i + sum_{j in row i, j != i} x_j
+ * x [n,K] -> y [n,N]; w1 [K,N], w2 [N,N] row-major ([in,out]: pass nn.Linear weights
+ * transposed); `act` is applied after BOTH linears (the reference reuses one act module,
+ * layers.py:26,29,55); affine = eval BatchNorm (bn_scale/bn_shift nullable).
+ * The aggregated tile and the hidden activation live in LDS only.  Shapes outside
+ * N in {64,128,256}, K % 4 == 0, K <= 256 return BLGNN_ERR_UNSUPPORTED (use
+ * blgnn_spmm_sum + 2 x blgnn_linear, which compute the same thing). */
+int blgnn_gin_layer(const int32_t *rowptr, const int32_t *col, int64_t nnz,
+                    const float *x, int64_t ldx, int32_t n, int32_t K,
+                    const float *w1, const float *b1, const float *w2,
+                    const float *b2, int32_t N, float eps, int32_t act,
+                    const float *act_param, const float *bn_scale,
+                    const float *bn_shift, float *y, int64_t ldy, void *stream);
+
 /* GCNConv: model/layers.py:23,52 (formula documented at
  * model/layers_meta.py:128-148).  Step 1: dis[i] = (1 + sum_{j!=i} w_ij)^-1/2
  * (inf -> 0).  */

@@ -76,6 +76,16 @@ def linear(x, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn
     return _put(out, _epi(v, act, act_param, bn_scale, bn_shift))
 
 
+def gin_layer_supported(csr, x, K, N):
+    return N in (64, 128, 256) and K % 4 == 0 and K <= 256 and csr.nnz < 12 * max(csr.n, 1)
+
+
+def gin_layer(csr, x, w1_kn, b1, w2_kn, b2, eps=0.0, act="identity", act_param=None,
+              bn_scale=None, bn_shift=None, out=None):
+    v = oracle.gin_conv(x, csr.edge_index, w1_kn.t(), b1, w2_kn.t(), b2, act, eps, act_param)
+    return _put(out, _epi(v, act, act_param, bn_scale, bn_shift))
+
+
 def gat_conv(csr, x, weight, att, bias, group="src", slope=0.2, act="identity", act_param=None,
              bn_scale=None, bn_shift=None, out=None, accumulate=False):
     v = oracle.gat_conv(x, csr.edge_index, weight, att, bias, group, slope)
@@ -134,7 +144,8 @@ def require_device(t, name="tensor"):
     return None
 
 
-NAMES = ["csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear", "gat_conv", "gcn_conv",
+NAMES = ["csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear", "gin_layer",
+         "gin_layer_supported", "gat_conv", "gcn_conv",
          "segment_reduce", "gmn_match", "edge_relu_sum", "row_degree", "pair_gather_normalize",
          "l2_normalize_rows", "scatter_rows", "require_device"]
 

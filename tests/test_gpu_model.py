@@ -154,7 +154,9 @@ def test_block_diagonal_independence_and_permutation(device):
     perm = np.random.default_rng(0).permutation(len(gids))
     pg = gids[perm]
     permuted = model(blgnn.BatchData(all_molecule_pairs(pg), ds, is_train=False, ignore_pairs=True))
-    assert torch.equal(permuted, full[torch.as_tensor(perm, device=device)])
+    # not bit-identical: a molecule that straddles a 64-row tile edge sums its out-of-tile
+    # neighbours after the in-tile ones, and tile edges move with the batch composition
+    assert max_err(permuted, full[torch.as_tensor(perm, device=device)]) < 1e-6
     sub = gids[100:140]
     part = model(blgnn.BatchData(all_molecule_pairs(sub), ds, is_train=False, ignore_pairs=True))
-    assert torch.equal(part, full[100:140])
+    assert max_err(part, full[100:140]) < 1e-6

@@ -116,6 +116,43 @@ def test_linear_epilogue(device, act):
     assert max_err(got, ref) < TOL
 
 
+@pytest.mark.parametrize("K,N,act", [(52, 64, "relu"), (52, 128, "relu"), (40, 256, "relu"), (64, 64, "identity"),
+                                     (128, 128, "relu"), (128, 128, "identity"), (256, 256, "relu"),
+                                     (256, 128, "prelu"), (64, 256, "tanh")])
+def test_gin_layer_fused(device, K, N, act):
+    """single-launch GIN layer == oracle GINConv -> act -> eval BN (model/layers.py:51-57)"""
+    ei, _, n = molecule_graph(37, 21)           # n is not a multiple of the 64-row tile
+    g = torch.Generator().manual_seed(K * 1000 + N)
+    x = torch.randn(n, K, generator=g)
+    w1, b1 = torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g) * 0.1
+    w2, b2 = torch.randn(N, N, generator=g) / N ** 0.5, torch.randn(N, generator=g) * 0.1
+    slope, scale, shift = torch.rand(N, generator=g), torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    D = lambda t: t.double()
+    ref = oracle.gin_conv(D(x), ei, D(w1), D(b1), D(w2), D(b2), act, eps=0.25, prelu_weight=D(slope))
+    ref = oracle.apply_act(ref, act, D(slope)) * D(scale) + D(shift)
+    dv = lambda t: t.to(device)
+    csr = ops.csr_from_edge_index(dv(ei), n)
+    assert ops.gin_layer_supported(csr, dv(x), K, N)
+    got = ops.gin_layer(csr, dv(x), dv(w1.t().contiguous()), dv(b1), dv(w2.t().contiguous()), dv(b2),
+                        eps=0.25, act=act, act_param=dv(slope), bn_scale=dv(scale), bn_shift=dv(shift))
+    assert max_err(got, ref) < TOL
+    # same numbers as the unfused three-kernel path, into a column slice
+    wide = torch.zeros(n, N + 8, device=device)
+    ops.gin_layer(csr, dv(x), dv(w1.t().contiguous()), dv(b1), dv(w2.t().contiguous()), dv(b2),
+                  eps=0.25, act=act, act_param=dv(slope), bn_scale=dv(scale), bn_shift=dv(shift),
+                  out=wide[:, 4:4 + N])
+    assert torch.equal(wide[:, 4:4 + N], got) and float(wide[:, :4].abs().max()) == 0.0
+
+
+def test_gin_layer_unsupported_shapes_are_reported(device):
+    ei, _, n = molecule_graph(5, 1)
+    csr = ops.csr_from_edge_index(ei.to(device), n)
+    x = torch.randn(n, 50, device=device)
+    assert not ops.gin_layer_supported(csr, x, 50, 64)
+    with pytest.raises(NotImplementedError):
+        ops.gin_layer(csr, x, torch.randn(50, 96, device=device), None, torch.randn(96, 96, device=device), None)
+
+
 @pytest.mark.parametrize("group", ["src", "dst"])
 @pytest.mark.parametrize("din,d", [(52, 64), (320, 64), (128, 128), (30, 50)])
 def test_gat_conv(device, group, din, d):
