@@ -59,7 +59,9 @@ class NodeAggregationPairs(nn.Module):
                     xs = model.acts[1:]
                 else:
                     xs = [x for i, x in enumerate(model.acts[1:]) if i % 2 == 1]
-                if isinstance(self.agg_func, _SegmentPool):
+                if isinstance(self.agg_func, _SegmentPool) and len(xs) <= 8:
+                    out = ops.segment_reduce_multi(seg, xs, self.agg_func.kind)
+                elif isinstance(self.agg_func, _SegmentPool):
                     G = seg.numel() - 1
                     widths = [x.shape[1] for x in xs]
                     out = torch.empty((G, sum(widths)), dtype=torch.float32, device=ins.device)

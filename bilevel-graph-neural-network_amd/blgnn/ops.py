@@ -12,7 +12,7 @@ from ._lib import call, ACT_IDS, GAT_GROUP, REDUCE_MEAN, REDUCE_SUM
 
 __all__ = [
     "CSR", "csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear",
-    "gat_conv", "gcn_conv", "segment_reduce", "gmn_match", "edge_relu_sum",
+    "gat_conv", "gcn_conv", "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum",
     "row_degree", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
     "require_device",
 ]
@@ -218,6 +218,25 @@ def segment_reduce(seg, x, kind="mean", out=None, row_map=None):
         raise ValueError("blgnn: out must have %d columns" % d)
     call("blgnn_segment_reduce", _vec(seg, "seg", torch.int32, False), G, xp, ldx, d,
          REDUCE_MEAN if kind == "mean" else REDUCE_SUM, op, ldo,
+         _vec(row_map, "row_map", torch.int32), _stream())
+    return out
+
+
+def segment_reduce_multi(seg, xs, kind="mean", row_map=None):
+    """torch.cat([scatter_mean(x, batch) for x in xs], dim=1) in one launch (<= 8 inputs)."""
+    import ctypes
+    if not 1 <= len(xs) <= 8:
+        raise ValueError("blgnn: segment_reduce_multi takes 1..8 inputs")
+    G = seg.numel() - 1
+    ptrs, lds, ds = [], [], []
+    for i, x in enumerate(xs):
+        p, ld = _mat(x, "xs[%d]" % i)
+        ptrs.append(p); lds.append(ld); ds.append(x.shape[1])
+    out = torch.empty((G, sum(ds)), dtype=torch.float32, device=xs[0].device)
+    n = len(xs)
+    call("blgnn_segment_reduce_multi", _vec(seg, "seg", torch.int32, False), G, n,
+         (ctypes.c_void_p * n)(*ptrs), (ctypes.c_int64 * n)(*lds), (ctypes.c_int32 * n)(*ds),
+         REDUCE_MEAN if kind == "mean" else REDUCE_SUM, out.data_ptr(), out.shape[1],
          _vec(row_map, "row_map", torch.int32), _stream())
     return out
 

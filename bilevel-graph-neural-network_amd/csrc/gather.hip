@@ -187,20 +187,29 @@ __global__ void __launch_bounds__(256) k_gather(const GatherArgs A) {
 }
 
 // "Wide row" variant for high-degree graphs (the interaction level: mean degree 20-60,
-// maximum in the hundreds).  One 256-thread workgroup per output row: the 4 waves x S =
-// 64/LG lane groups are 4*S edge slots that stride over the row's CSR segment, two edges in
-// flight per slot; partial rows meet by wave shuffles, then in LDS ([4][d]) in a fixed order
-// (deterministic).  A kernel that gives each row to ONE lane group runs as long as its
-// heaviest row: 241 us vs ~20 us for the upper GAT of the DrugBank-shape graph.
+// maximum in the hundreds).  One 256-thread workgroup per output row.  Per pass of 256 edges:
+//  (a) every thread takes ONE edge: reads its column index and computes its weight (for GAT the
+//      s_src / max / denominator gathers and the exp run 256-wide instead of once per lane
+//      group), parks (j, w) in LDS;
+//  (b) the 4 waves x S = 64/LG lane groups are 4*S edge slots striding over the parked edges,
+//      eight neighbour rows in flight per slot (coalesced 16 B/lane row reads from L2).
+// Partial rows meet by wave shuffles, then in LDS ([4][d]) in a fixed order (deterministic).
+// A kernel that gives each row to ONE lane group runs as long as its heaviest row: 241 us vs
+// ~20 us for the upper GAT of the DrugBank-shape graph.
+constexpr int WIDE_EDGES = 256;
+
 template <int MODE, int LG, int CH>
 __global__ void __launch_bounds__(256) k_gather_wide(const GatherArgs A) {
     constexpr int S = WAVE / LG;                 // edge slots per wave
     constexpr int NSLOT = 4 * S;
-    extern __shared__ float4 part4[];            // [4][d4]
+    constexpr int U = CH <= 1 ? 8 : (CH <= 2 ? 4 : 2);   // neighbour rows in flight per slot
+    extern __shared__ float4 part4[];            // [4][d4] float4, then the parked edges
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
     const int sub = lane / LG, l = lane % LG;
     const int slot = wid * S + sub;
     const int d4 = A.d >> 2;
+    int *js = reinterpret_cast<int *>(part4 + 4 * d4);
+    float *ws = reinterpret_cast<float *>(js + WIDE_EDGES);
     const float4 *__restrict__ X = reinterpret_cast<const float4 *>(A.x);
     const int64_t ldx4 = A.ldx >> 2, ldy4 = A.ldy >> 2, ldp4 = A.ldp >> 2;
 
@@ -228,44 +237,56 @@ __global__ void __launch_bounds__(256) k_gather_wide(const GatherArgs A) {
             }
         }
         const int e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
-        for (int e = e0 + slot; e < e1; e += 2 * NSLOT) {
-            int j[2];
-            float w[2];
-            float4 v[2][CH];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int ee = e + u * NSLOT;
-                const bool in = ee < e1;
-                j[u] = in ? A.col[ee] : row;
-                w[u] = in ? ctx.edge_w(A, row, j[u], ee) : 0.f;
+        for (int base = e0; base < e1; base += WIDE_EDGES) {
+            {   // (a) one edge per thread
+                const int ee = base + threadIdx.x;
+                int j = row;
+                float w = 0.f;
+                if (ee < e1) { j = A.col[ee]; w = ctx.edge_w(A, row, j, ee); }
+                js[threadIdx.x] = j;
+                ws[threadIdx.x] = w;
             }
+            __syncthreads();
+            const int cnt = (e1 - base) < WIDE_EDGES ? (e1 - base) : WIDE_EDGES;
+            for (int t = slot; t < cnt; t += U * NSLOT) {
+                int j[U];
+                float w[U];
+                float4 v[U][CH];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (w[u] != 0.f) {
-                    const float4 *R = X + (int64_t)j[u] * ldx4;
-#pragma unroll
-                    for (int k = 0; k < CH; ++k) if (ok[k]) v[u][k] = R[l + k * LG];
+                for (int u = 0; u < U; ++u) {
+                    const int tt = t + u * NSLOT;
+                    j[u] = tt < cnt ? js[tt] : row;
+                    w[u] = tt < cnt ? ws[tt] : 0.f;
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (w[u] != 0.f) {
+                for (int u = 0; u < U; ++u) {
+                    if (w[u] != 0.f) {
+                        const float4 *R = X + (int64_t)j[u] * ldx4;
 #pragma unroll
-                    for (int k = 0; k < CH; ++k) {
-                        if (!ok[k]) continue;
-                        if (MODE == MODE_RELU) {
-                            acc[k].x += fmaxf(prow[k].x + v[u][k].x, 0.f);
-                            acc[k].y += fmaxf(prow[k].y + v[u][k].y, 0.f);
-                            acc[k].z += fmaxf(prow[k].z + v[u][k].z, 0.f);
-                            acc[k].w += fmaxf(prow[k].w + v[u][k].w, 0.f);
-                        } else if (MODE == MODE_SUM && !A.w) {
-                            f4_add(acc[k], v[u][k]);
-                        } else {
-                            f4_fma(acc[k], w[u], v[u][k]);
+                        for (int k = 0; k < CH; ++k) if (ok[k]) v[u][k] = R[l + k * LG];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (w[u] != 0.f) {
+#pragma unroll
+                        for (int k = 0; k < CH; ++k) {
+                            if (!ok[k]) continue;
+                            if (MODE == MODE_RELU) {
+                                acc[k].x += fmaxf(prow[k].x + v[u][k].x, 0.f);
+                                acc[k].y += fmaxf(prow[k].y + v[u][k].y, 0.f);
+                                acc[k].z += fmaxf(prow[k].z + v[u][k].z, 0.f);
+                                acc[k].w += fmaxf(prow[k].w + v[u][k].w, 0.f);
+                            } else if (MODE == MODE_SUM && !A.w) {
+                                f4_add(acc[k], v[u][k]);
+                            } else {
+                                f4_fma(acc[k], w[u], v[u][k]);
+                            }
                         }
                     }
                 }
             }
+            __syncthreads();                     // parked edges consumed before the next pass
         }
         // slots of one wave -> lane group 0
 #pragma unroll
@@ -361,7 +382,8 @@ static void launch_vec(const GatherArgs &A, hipStream_t s) {
 template <int MODE, int LG, int CH>
 static void launch_wide(const GatherArgs &A, hipStream_t s) {
     const int blocks = A.n < 256 * 32 ? A.n : 256 * 32;
-    hipLaunchKernelGGL((k_gather_wide<MODE, LG, CH>), dim3(blocks), dim3(256), (size_t)A.d * 16, s, A);
+    hipLaunchKernelGGL((k_gather_wide<MODE, LG, CH>), dim3(blocks), dim3(256),
+                       (size_t)A.d * 16 + WIDE_EDGES * 8, s, A);
 }
 
 // rows this heavy on average go one-workgroup-per-row (see k_gather_wide)

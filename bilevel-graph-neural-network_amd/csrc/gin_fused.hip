@@ -20,6 +20,7 @@
 // HBM traffic = read x once + write y once (the algorithmic bytes of the SpMM alone); the
 // two GEMMs ride on top until the fp32 MFMA roof.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace blgnn {
 
@@ -42,7 +43,7 @@ __device__ unsigned long long g_gin_stamps[16];
 #define STAMP(i)
 #endif
 
-constexpr int GBM = 64;     // rows per workgroup
+static int g_gin_small_rows = 1 << 18;   // below this many rows use 32-row tiles
 constexpr int KC = 32;      // K chunk (two-level accumulation, see linear.hip)
 constexpr int GCOLS = 1024; // column indices of a tile kept in LDS (64 rows x mean degree 2.1 = 136)
 
@@ -139,8 +140,8 @@ __device__ __forceinline__ void tile_to_lds(const f32x16 (&acc)[MT][NTW], float 
     }
 }
 
-template <int N, int WCOLS, int LG, int ACT>
-__global__ void __launch_bounds__(256, 2) k_gin_layer(const GinArgs A) {
+template <int N, int WCOLS, int LG, int ACT, int GBM>
+__global__ void __launch_bounds__(256, (GBM == 32 && N <= 128) ? 4 : 2) k_gin_layer(const GinArgs A) {
     constexpr int WROWS = 4 / WCOLS;
     constexpr int MT = GBM / 32 / WROWS;
     constexpr int NTW = N / 32 / WCOLS;
@@ -311,48 +312,48 @@ __global__ void __launch_bounds__(256, 2) k_gin_layer(const GinArgs A) {
     STAMP(6);
 }
 
-static size_t gin_lds_bytes(int K, int N) {
+static size_t gin_lds_bytes(int K, int N, int GBM) {
     const int Kpad = (K + KC - 1) / KC * KC;
     const size_t r0 = (size_t)GBM * ((Kpad + 1) > (N + 4) ? (Kpad + 1) : (N + 4));
     const size_t r1 = (size_t)GBM * (K > N + 1 ? K : N + 1);
     return sizeof(float) * (r0 + r1 + GBM + 4 + GCOLS);
 }
 
-template <int N, int WCOLS, int LG, int ACT>
+template <int N, int WCOLS, int LG, int ACT, int GBM>
 static int launch_gin(const GinArgs &A, hipStream_t s) {
     // opt in to more than 64 KiB of dynamic LDS, but only to what this shape needs: the limit
     // that is declared, not the amount that is launched, is what the dispatcher budgets per
     // workgroup (declaring 160 KiB pinned the kernel to ONE workgroup per CU).
     static size_t declared = 0;                     // per instantiation; monotone, benign race
-    const size_t bytes = gin_lds_bytes(A.K, N);
+    const size_t bytes = gin_lds_bytes(A.K, N, GBM);
     if (bytes > declared) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gin_layer<N, WCOLS, LG, ACT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gin_layer<N, WCOLS, LG, ACT, GBM>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
             return fail(BLGNN_ERR_LAUNCH, "gin_layer: cannot raise the dynamic LDS limit to %zu bytes", bytes);
         declared = bytes;
     }
     const int blocks = (A.n + GBM - 1) / GBM;
-    hipLaunchKernelGGL((k_gin_layer<N, WCOLS, LG, ACT>), dim3(blocks), dim3(256), bytes, s, A);
+    hipLaunchKernelGGL((k_gin_layer<N, WCOLS, LG, ACT, GBM>), dim3(blocks), dim3(256), bytes, s, A);
     return launch_status("gin_layer");
 }
 
-template <int N, int WCOLS, int LG>
+template <int N, int WCOLS, int LG, int GBM>
 static int pick_act(const GinArgs &A, hipStream_t s) {
     switch (A.epi.act) {
-        case BLGNN_ACT_RELU:    return launch_gin<N, WCOLS, LG, BLGNN_ACT_RELU>(A, s);
-        case BLGNN_ACT_PRELU:   return launch_gin<N, WCOLS, LG, BLGNN_ACT_PRELU>(A, s);
-        case BLGNN_ACT_SIGMOID: return launch_gin<N, WCOLS, LG, BLGNN_ACT_SIGMOID>(A, s);
-        case BLGNN_ACT_TANH:    return launch_gin<N, WCOLS, LG, BLGNN_ACT_TANH>(A, s);
-        default:                return launch_gin<N, WCOLS, LG, BLGNN_ACT_IDENTITY>(A, s);
+        case BLGNN_ACT_RELU:    return launch_gin<N, WCOLS, LG, BLGNN_ACT_RELU, GBM>(A, s);
+        case BLGNN_ACT_PRELU:   return launch_gin<N, WCOLS, LG, BLGNN_ACT_PRELU, GBM>(A, s);
+        case BLGNN_ACT_SIGMOID: return launch_gin<N, WCOLS, LG, BLGNN_ACT_SIGMOID, GBM>(A, s);
+        case BLGNN_ACT_TANH:    return launch_gin<N, WCOLS, LG, BLGNN_ACT_TANH, GBM>(A, s);
+        default:                return launch_gin<N, WCOLS, LG, BLGNN_ACT_IDENTITY, GBM>(A, s);
     }
 }
 
-template <int N, int WCOLS>
+template <int N, int WCOLS, int GBM>
 static int pick_lg(const GinArgs &A, hipStream_t s) {
     const int k4 = A.K / 4;
-    if (k4 <= 16) return pick_act<N, WCOLS, 16>(A, s);
-    if (k4 <= 32) return pick_act<N, WCOLS, 32>(A, s);
-    return pick_act<N, WCOLS, 64>(A, s);
+    if (k4 <= 16) return pick_act<N, WCOLS, 16, GBM>(A, s);
+    if (k4 <= 32) return pick_act<N, WCOLS, 32, GBM>(A, s);
+    return pick_act<N, WCOLS, 64, GBM>(A, s);
 }
 
 }  // namespace blgnn
@@ -381,7 +382,12 @@ extern "C" int blgnn_gin_layer(const int32_t *rowptr, const int32_t *col, int64_
     A.epi = Epilogue{b2, act_param, bn_scale, bn_shift, act};
     A.y = y; A.ldy = ldy;
     hipStream_t s = (hipStream_t)stream;
-    if (N == 256) return pick_lg<256, 4>(A, s);
-    if (N == 128) return pick_lg<128, 4>(A, s);
-    return pick_lg<64, 2>(A, s);
+    // 32-row tiles (4 waves side by side over N) halve the LDS footprint -> twice the resident
+    // workgroups per CU, and halve the work quantum -> a shorter tail when the grid is only a
+    // few tiles per CU; 64-row tiles reuse each weight fragment twice and win on big inputs.
+    const char *force = getenv("BLGNN_GIN_ROWS");
+    const bool small = force ? (atoi(force) == 32) : (n < g_gin_small_rows);
+    if (N == 256) return (small || !force) ? pick_lg<256, 4, 32>(A, s) : pick_lg<256, 4, 64>(A, s);
+    if (N == 128) return small ? pick_lg<128, 4, 32>(A, s) : pick_lg<128, 4, 64>(A, s);
+    return pick_lg<64, 2, 64>(A, s);
 }

@@ -9,11 +9,21 @@ namespace blgnn {
 // of the segment; each lane owns float4 columns c4 = lane, lane+64, ...  Partial
 // sums meet in LDS ([4][d] floats) and wave 0 writes the reduced row.
 // Rows are added in a fixed order -> bitwise reproducible.
+constexpr int SEG_MAX_INPUTS = 8;
+struct SegInputs {                                     // blockIdx.y selects the input
+    const float *x[SEG_MAX_INPUTS];
+    int64_t ldx[SEG_MAX_INPUTS];
+    int32_t d[SEG_MAX_INPUTS], col0[SEG_MAX_INPUTS], vec[SEG_MAX_INPUTS];
+};
+
 __global__ void __launch_bounds__(256)
-k_segment_reduce(const int32_t *__restrict__ seg, int32_t G, const float *__restrict__ x,
-                 int64_t ldx, int32_t d, int32_t kind, float *__restrict__ out, int64_t ldo,
-                 const int32_t *__restrict__ row_map, int vec) {
+k_segment_reduce(const int32_t *__restrict__ seg, int32_t G, const SegInputs in, int32_t kind,
+                 float *__restrict__ out_base, int64_t ldo, const int32_t *__restrict__ row_map) {
     extern __shared__ float part[];                    // [4][d]
+    const float *__restrict__ x = in.x[blockIdx.y];
+    const int64_t ldx = in.ldx[blockIdx.y];
+    const int d = in.d[blockIdx.y], vec = in.vec[blockIdx.y];
+    float *__restrict__ out = out_base + in.col0[blockIdx.y];
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
     for (int g = blockIdx.x; g < G; g += gridDim.x) {
         const int r0 = seg[g], r1 = seg[g + 1];
@@ -116,21 +126,45 @@ static int wave_grid(int64_t items) {
     return (int)b;
 }
 
+static int segment_reduce_launch(const int32_t *seg, int32_t G, int32_t num, const float *const *xs,
+                                 const int64_t *ldxs, const int32_t *ds, int32_t kind, float *out,
+                                 int64_t ldo, const int32_t *row_map, hipStream_t stream, const char *what) {
+    BLGNN_CHECK_ARG(G >= 0 && num >= 1 && num <= SEG_MAX_INPUTS, "%s: bad G / number of inputs", what);
+    BLGNN_CHECK_ARG(kind == BLGNN_REDUCE_SUM || kind == BLGNN_REDUCE_MEAN, "%s: bad kind", what);
+    if (G == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(seg && out && xs && ldxs && ds, "%s: null pointer", what);
+    SegInputs in = {};
+    int dmax = 0, col = 0;
+    for (int i = 0; i < num; ++i) {
+        BLGNN_CHECK_ARG(ds[i] >= 0 && (ds[i] == 0 || xs[i]) && ldxs[i] >= ds[i], "%s: bad input %d", what, i);
+        in.x[i] = xs[i]; in.ldx[i] = ldxs[i]; in.d[i] = ds[i]; in.col0[i] = col;
+        in.vec[i] = (ds[i] % 4 == 0) && (ldxs[i] % 4 == 0) && aligned16(xs[i]);
+        col += ds[i];
+        dmax = ds[i] > dmax ? ds[i] : dmax;
+    }
+    BLGNN_CHECK_ARG(ldo >= col, "%s: output leading dimension < total width", what);
+    if (dmax == 0) return BLGNN_OK;
+    if ((size_t)dmax * 16 > 64 * 1024)
+        return fail(BLGNN_ERR_UNSUPPORTED, "%s: d=%d needs more than 64 KiB of LDS", what, dmax);
+    const int blocks = G < 256 * 16 ? G : 256 * 16;
+    hipLaunchKernelGGL(k_segment_reduce, dim3(blocks, num), dim3(256), (size_t)dmax * 16, stream, seg, G,
+                       in, kind, out, ldo, row_map);
+    return launch_status(what);
+}
+
 extern "C" int blgnn_segment_reduce(const int32_t *seg, int32_t G, const float *x, int64_t ldx,
                                     int32_t d, int32_t kind, float *out, int64_t ldo,
                                     const int32_t *row_map, void *stream) {
-    BLGNN_CHECK_ARG(G >= 0 && d >= 0, "segment_reduce: negative size");
-    BLGNN_CHECK_ARG(kind == BLGNN_REDUCE_SUM || kind == BLGNN_REDUCE_MEAN, "segment_reduce: bad kind");
-    if (G == 0 || d == 0) return BLGNN_OK;
-    BLGNN_CHECK_ARG(seg && x && out, "segment_reduce: null pointer");
-    BLGNN_CHECK_ARG(ldx >= d && ldo >= d, "segment_reduce: leading dimension < d");
-    if ((size_t)d * 16 > 160 * 1024)
-        return fail(BLGNN_ERR_UNSUPPORTED, "segment_reduce: d=%d needs more than 160 KiB of LDS", d);
-    const int vec = (d % 4 == 0) && (ldx % 4 == 0) && aligned16(x);
-    const int blocks = G < 256 * 16 ? G : 256 * 16;
-    hipLaunchKernelGGL(k_segment_reduce, dim3(blocks), dim3(256), (size_t)d * 16, (hipStream_t)stream,
-                       seg, G, x, ldx, d, kind, out, ldo, row_map, vec);
-    return launch_status("segment_reduce");
+    return segment_reduce_launch(seg, G, 1, &x, &ldx, &d, kind, out, ldo, row_map, (hipStream_t)stream,
+                                 "segment_reduce");
+}
+
+extern "C" int blgnn_segment_reduce_multi(const int32_t *seg, int32_t G, int32_t num_inputs,
+                                          const float *const *xs_host, const int64_t *ldxs_host,
+                                          const int32_t *ds_host, int32_t kind, float *out, int64_t ldo,
+                                          const int32_t *row_map, void *stream) {
+    return segment_reduce_launch(seg, G, num_inputs, xs_host, ldxs_host, ds_host, kind, out, ldo, row_map,
+                                 (hipStream_t)stream, "segment_reduce_multi");
 }
 
 extern "C" int blgnn_pair_gather_normalize(const float *z, int64_t ldz, const int64_t *ids1,

@@ -167,6 +167,15 @@ int blgnn_segment_reduce(const int32_t *seg, int32_t G, const float *x,
                          int64_t ldx, int32_t d, int32_t kind, float *out,
                          int64_t ldo, const int32_t *row_map, void *stream);
 
+/* Multi-scale readout in ONE launch: model/layers_aggregation.py:32-39
+ * (torch.cat([agg(x, batch) for x in acts], dim=1)).  xs_host / ldxs_host / ds_host are HOST
+ * arrays of num_inputs (<= 8) device pointers, leading dimensions and widths; input i is
+ * reduced into columns [sum_{k<i} d_k, +d_i) of out. */
+int blgnn_segment_reduce_multi(const int32_t *seg, int32_t G, int32_t num_inputs,
+                               const float *const *xs_host, const int64_t *ldxs_host,
+                               const int32_t *ds_host, int32_t kind, float *out,
+                               int64_t ldo, const int32_t *row_map, void *stream);
+
 /* ---- dense feature transform (fp32 MFMA) -------------------------------- */
 
 /* Y = epi(X[M,K] @ W[K,N] + bias) (+ addend),  epi = act then per-channel affine.

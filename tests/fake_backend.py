@@ -113,6 +113,10 @@ def segment_reduce(seg, x, kind="mean", out=None, row_map=None):
     return out
 
 
+def segment_reduce_multi(seg, xs, kind="mean", row_map=None):
+    return torch.cat([segment_reduce(seg, x, kind) for x in xs], dim=1)
+
+
 def gmn_match(seg, x, out=None):
     s = seg.tolist()
     return _put(out, oracle.gmn_match(x, [(s[i], s[i + 1]) for i in range(len(s) - 1)]))
@@ -146,7 +150,7 @@ def require_device(t, name="tensor"):
 
 NAMES = ["csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear", "gin_layer",
          "gin_layer_supported", "gat_conv", "gcn_conv",
-         "segment_reduce", "gmn_match", "edge_relu_sum", "row_degree", "pair_gather_normalize",
+         "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum", "row_degree", "pair_gather_normalize",
          "l2_normalize_rows", "scatter_rows", "require_device"]
 
 

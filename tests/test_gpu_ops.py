@@ -217,6 +217,20 @@ def test_segment_reduce(device, kind, d):
     assert max_err(wide[rows.long(), 4:4 + d], ref) < TOL
 
 
+def test_segment_reduce_multi_scale(device):
+    sizes = [3, 0, 1, 40, 200, 2]
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.as_tensor(sizes))
+    n = int(sum(sizes))
+    wide = torch.randn(n, 300)
+    xs = [torch.randn(n, 64), torch.randn(n, 128), wide[:, 10:60], torch.randn(n, 52), torch.randn(n, 256)]
+    ref = oracle.node_aggregation([x.double() for x in xs], batch, len(sizes), "avg_pool")
+    seg = ops.segments_from_batch(batch.to(device), len(sizes))
+    dw = wide.to(device)
+    got = ops.segment_reduce_multi(seg, [xs[0].to(device), xs[1].to(device), dw[:, 10:60], xs[3].to(device),
+                                         xs[4].to(device)], "mean")
+    assert got.shape == ref.shape and max_err(got, ref) < TOL
+
+
 @pytest.mark.parametrize("d,sizes", [(64, [5, 7, 1, 3, 24, 24]), (256, [40, 38, 2, 70, 64, 65]),
                                      (512, [30, 31]), (256, [150, 170]), (128, [457, 12])])
 def test_gmn_match(device, d, sizes):
