@@ -115,12 +115,17 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = "cuda:%d" % local_rank
+    # BLGNN_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks
+    backend = os.environ.get("BLGNN_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = "cuda:%d" % dev_index
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device(device))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import blgnn
     from blgnn import ops
@@ -158,53 +163,71 @@ def main():
                                               4.0 * x.shape[0] * (x.shape[1] + w1.shape[1]) + 4.0 * csr.nnz + 4.0 * (csr.n + 1)),
         lambda *a, **kw: True)
 
-    def step(i):
+    def lower_part():
         with torch.no_grad():
             model.acts = [lower_batch.merge_data['merge'].x]
             for layer in lower_layers:
                 model.acts.append(layer(model.acts[-1], lower_batch, model))
-            pooled = model.acts[-1]
-            if world > 1:
-                sharded.gather_init_x(pooled, out=graph.init_x)
+            return model.acts[-1]                      # pooled rows of this rank's drugs
+
+    def exchange(pooled):
+        if world > 1:                                  # the one collective of the path
+            sharded.gather_init_x(pooled, out=graph.init_x)
+
+    def upper_part(i):
+        with torch.no_grad():
             b = upper_batches[i % n_batches]
             model.acts = [b.merge_data['merge'].x]
             for layer in upper_layers:
                 model.acts.append(layer(model.acts[-1], b, model))
             return model.acts[-1]
 
-    # The forward is ~45 short launches: captured once per distinct pair batch into a HIP graph
-    # (launch-bound inner loops belong in graphs) and replayed in the timed region.  RCCL
-    # collectives stay outside graphs: with N > 1 the step runs eagerly.
-    use_graph = (not args.no_graph) and world == 1
-    for i in range(max(args.warmup, 3)):
-        step(i)
+    def step(i):
+        exchange(lower_part())
+        return upper_part(i)
+
+    # The forward is ~40 short launches: captured into HIP graphs (launch-bound inner loops
+    # belong in graphs) and replayed in the timed region.  N = 1: one graph per distinct pair
+    # batch holds the whole forward.  N > 1: the RCCL all-gather stays outside capture -- one
+    # graph for the lower level, the collective, one graph per pair batch for the upper level.
+    use_graph = not args.no_graph
+    for i in range(max(args.warmup, n_batches)):       # every batch once: host->device id copies
+        step(i)                                        # and CSR builds must not fall into a capture
     torch.cuda.synchronize()
-    graphs, outs = [], []
+    g_lower, g_upper, pooled_static, outs = None, [], None, []
     if use_graph:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            if world > 1:
+                g_lower = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_lower, stream=side):
+                    pooled_static = lower_part()
             for i in range(n_batches):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side):
-                    outs.append(step(i))
-                graphs.append(g)
+                    outs.append(upper_part(i) if world > 1 else step(i))
+                g_upper.append(g)
         torch.cuda.current_stream().wait_stream(side)
-        for i in range(args.warmup):
-            graphs[i % n_batches].replay()
+
+    def replay(i):
+        if world > 1:
+            g_lower.replay()
+            exchange(pooled_static)
+        g_upper[i % n_batches].replay()
+        return outs[i % n_batches]
+
+    run = replay if use_graph else step
+    for i in range(args.warmup):
+        run(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if use_graph:
-        for i in range(args.steps):
-            graphs[i % n_batches].replay()
-        preds = outs[(args.steps - 1) % n_batches]
-    else:
-        timer.enabled = True
-        for i in range(args.steps):
-            preds = step(i)
+    timer.enabled = not use_graph
+    for i in range(args.steps):
+        preds = run(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
