@@ -365,10 +365,9 @@ extern "C" int blgnn_gin_layer(const int32_t *rowptr, const int32_t *col, int64_
                                const float *w2, const float *b2, int32_t N, float eps, int32_t act,
                                const float *act_param, const float *bn_scale, const float *bn_shift,
                                float *y, int64_t ldy, void *stream) {
-    (void)nnz;
-    BLGNN_CHECK_ARG(n >= 0 && K > 0 && N > 0, "gin_layer: bad sizes");
+    BLGNN_CHECK_ARG(n >= 0 && K > 0 && N > 0 && nnz >= 0, "gin_layer: bad sizes");
     if (n == 0) return BLGNN_OK;
-    BLGNN_CHECK_ARG(rowptr && col && x && w1 && w2 && y, "gin_layer: null pointer");
+    BLGNN_CHECK_ARG(rowptr && (col || nnz == 0) && x && w1 && w2 && y, "gin_layer: null pointer");
     BLGNN_CHECK_ARG(ldx >= K && ldy >= N, "gin_layer: leading dimension too small");
     BLGNN_CHECK_ARG(act >= 0 && act <= BLGNN_ACT_TANH, "gin_layer: bad activation id");
     BLGNN_CHECK_ARG(x != y, "gin_layer: x and y must not alias");

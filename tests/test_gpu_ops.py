@@ -74,6 +74,24 @@ def test_spmm_gin_aggregate(device, d):
     assert max_err(got, ref) < TOL
 
 
+def test_graph_without_edges(device):
+    """batch of single-atom molecules: nnz = 0 everywhere on the path"""
+    n, d = 37, 64
+    ei = torch.zeros((2, 0), dtype=torch.int64, device=device)
+    csr = ops.csr_from_edge_index(ei, n)
+    x = torch.randn(n, d)
+    assert max_err(ops.spmm_sum(csr, x.to(device), 1.0, True), x) < TOL
+    W, att, b = torch.randn(d, d) / 8, torch.randn(1, 1, 2 * d), torch.randn(d)
+    ref = oracle.gat_conv(x.double(), ei.cpu(), W.double(), att.double(), b.double(), "src")
+    assert max_err(ops.gat_conv(csr, x.to(device), W.to(device), att.to(device), b.to(device)), ref) < TOL
+    ref = oracle.gcn_conv(x.double(), ei.cpu(), W.double(), b.double())
+    assert max_err(ops.gcn_conv(csr, x.to(device), W.to(device), b.to(device)), ref) < TOL
+    w2 = torch.randn(d, d) / 8
+    ref = torch.relu(oracle.gin_conv(x.double(), ei.cpu(), W.t().double(), b.double(), w2.t().double(), b.double(), "relu"))
+    got = ops.gin_layer(csr, x.to(device), W.to(device), b.to(device), w2.to(device), b.to(device), act="relu")
+    assert max_err(got, ref) < TOL
+
+
 def test_spmm_weighted_selfloops_highdeg(device):
     n, d = 700, 128
     ei = rand_graph(n, 60, 7, self_loops=True, isolated=5)
