@@ -253,6 +253,14 @@ def main():
     out = None
     if rank == 0:
         value = world * BATCH_PAIRS * args.steps / elapsed
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+        # (profiles/summarize_pmc.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction)
+        traffic = None
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_gin_layer_pmc_summary.json")))[
+                "hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         tflops = sum(w[0] for w in work) / (sum(ms) * 1e-3) / 1e12 if ms else 0.0
         alg_gbps = sum(w[1] for w in work) / (sum(ms) * 1e-3) / 1e9 if ms else 0.0
         out = {
@@ -269,7 +277,8 @@ def main():
                        "parallelism": "molecule/pair shards x%d + all-gather(pooled)" % world},
             "roofline": {"kernel": "k_gin_layer (fused GIN layer: CSR gather + 2 fp32-MFMA GEMMs + act/BN)",
                          "bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "alg_bytes_per_launch": sum(w[1] for w in work) / max(len(work), 1),
                          "launches": len(ms), "avg_us": 1e3 * sum(ms) / max(len(ms), 1),
                          "alg_hbm_GBps": alg_gbps, "alg_hbm_frac": alg_gbps / PEAK_HBM_GBPS},
         }

@@ -14,7 +14,7 @@
 namespace blgnn {
 
 template <int CH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 k_gmn_match(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__restrict__ x,
             int64_t ldx, float *__restrict__ u, int64_t ldu, int32_t d, int32_t lds_floats) {
     extern __shared__ float4 smem4[];
@@ -37,7 +37,7 @@ k_gmn_match(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__r
         }
         __syncthreads();
 
-        for (int t = wid; t < nt; t += 4) {
+        for (int t = wid; t < nt; t += (int)(blockDim.x / WAVE)) {
             const bool first = t < n1;
             const int arow_g = s0 + t;                     // global row of the query node
             const int b0 = first ? n1 : 0;                 // partner rows (local index)
@@ -60,31 +60,43 @@ k_gmn_match(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__r
 #pragma unroll
             for (int k = 0; k < CH; ++k) acc[k] = f4_zero();
 
-            for (int j0 = 0; j0 < nb; j0 += WAVE) {
-                const int j = j0 + lane;
+            // small partner graphs leave most of the 64 lanes idle with one lane per partner row;
+            // P lanes share a row (each takes 1/P of the feature range) when nb <= 64/P
+            const int P = nb <= 16 ? 4 : (nb <= 32 ? 2 : 1);
+            const int rows_per_chunk = WAVE / P;
+            for (int j0 = 0; j0 < nb; j0 += rows_per_chunk) {
+                const int jloc = lane % rows_per_chunk, part = lane / rows_per_chunk;
+                const int j = j0 + jloc;
                 const bool live = j < nb;
                 float s = -INFINITY;
-                if (live) {
-                    const float *brow = Bbase + (int64_t)j * bld;
+                {
                     float dot = 0.f, nbq = 0.f;
-                    for (int k4 = 0; k4 < d4; ++k4) {
-                        const float4 b = *reinterpret_cast<const float4 *>(brow + 4 * k4);
-                        const float4 a = *reinterpret_cast<const float4 *>(arow + 4 * k4);
-                        dot = fmaf(a.x, b.x, dot); dot = fmaf(a.y, b.y, dot);
-                        dot = fmaf(a.z, b.z, dot); dot = fmaf(a.w, b.w, dot);
-                        nbq = fmaf(b.x, b.x, nbq); nbq = fmaf(b.y, b.y, nbq);
-                        nbq = fmaf(b.z, b.z, nbq); nbq = fmaf(b.w, b.w, nbq);
+                    if (live) {
+                        const float *brow = Bbase + (int64_t)j * bld;
+                        const int k_lo = (part * d4) / P, k_hi = ((part + 1) * d4) / P;
+                        for (int k4 = k_lo; k4 < k_hi; ++k4) {
+                            const float4 b = *reinterpret_cast<const float4 *>(brow + 4 * k4);
+                            const float4 a = *reinterpret_cast<const float4 *>(arow + 4 * k4);
+                            dot = fmaf(a.x, b.x, dot); dot = fmaf(a.y, b.y, dot);
+                            dot = fmaf(a.z, b.z, dot); dot = fmaf(a.w, b.w, dot);
+                            nbq = fmaf(b.x, b.x, nbq); nbq = fmaf(b.y, b.y, nbq);
+                            nbq = fmaf(b.z, b.z, nbq); nbq = fmaf(b.w, b.w, nbq);
+                        }
                     }
-                    s = dot * inva * (1.f / fmaxf(sqrtf(nbq), 1e-12f));
+                    for (int off = rows_per_chunk; off < WAVE; off <<= 1) {      // combine the P parts
+                        dot += __shfl_xor(dot, off, WAVE);
+                        nbq += __shfl_xor(nbq, off, WAVE);
+                    }
+                    if (live) s = dot * inva * (1.f / fmaxf(sqrtf(nbq), 1e-12f));
                 }
                 const float m_new = fmaxf(m_run, group_max(s, WAVE));
                 const float resc = expf(m_run - m_new);          // 0 on the first chunk
                 const float p = live ? expf(s - m_new) : 0.f;
-                l_run = l_run * resc + group_sum(p, WAVE);
+                l_run = l_run * resc + group_sum(part == 0 ? p : 0.f, WAVE);
                 m_run = m_new;
 #pragma unroll
                 for (int k = 0; k < CH; ++k) { acc[k].x *= resc; acc[k].y *= resc; acc[k].z *= resc; acc[k].w *= resc; }
-                const int cnt = (nb - j0) < WAVE ? (nb - j0) : WAVE;
+                const int cnt = (nb - j0) < rows_per_chunk ? (nb - j0) : rows_per_chunk;
                 for (int jj = 0; jj < cnt; ++jj) {
                     const float pj = __shfl(p, jj, WAVE);
                     const float *brow = Bbase + (int64_t)(j0 + jj) * bld;
@@ -130,16 +142,31 @@ extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const floa
         return fail(BLGNN_ERR_UNSUPPORTED,
                     "gmn_match: needs d, ldx, ldu multiples of 4 and 16-byte aligned pointers");
     if (d > 2048) return fail(BLGNN_ERR_UNSUPPORTED, "gmn_match: d=%d > 2048", d);
-    // LDS budget: two workgroups per CU when the typical pair (<= ~72 rows at d=256) fits
-    // in 64 KiB, which is also the largest dynamic-LDS size that needs no opt-in.
-    const int lds_bytes = 64 * 1024;
+    // LDS budget: room for a 128-row pair (the p95 of DrugBank/DrugCombo pairs is ~112 rows;
+    // a pair that does not fit reads its partner rows from L2 with one row per lane, which is
+    // an order of magnitude slower), between 64 KiB (two 256-thread workgroups per CU) and
+    // 150 KiB (one 512-thread workgroup per CU).
+    size_t want = (size_t)128 * (d + 4) * sizeof(float);
+    if (want < 64 * 1024) want = 64 * 1024;
+    if (want > 150 * 1024) want = 150 * 1024;
+    const int lds_bytes = (int)want;
     const int lds_floats = lds_bytes / 4;
+    const int threads = lds_bytes > 80 * 1024 ? 512 : 256;
     const int blocks = num_pairs < 256 * 8 ? num_pairs : 256 * 8;
     hipStream_t s = (hipStream_t)stream;
     const int ch = (d / 4 + WAVE - 1) / WAVE;
-#define BLGNN_GMN_LAUNCH(CH_)                                                                   \
-    hipLaunchKernelGGL((k_gmn_match<CH_>), dim3(blocks), dim3(256), lds_bytes, s, seg, num_pairs, \
-                       x, ldx, u, ldu, d, lds_floats)
+#define BLGNN_GMN_LAUNCH(CH_)                                                                       \
+    do {                                                                                            \
+        static int declared = 0;                                                                    \
+        if (lds_bytes > declared) {                                                                 \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gmn_match<CH_>),              \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) \
+                return fail(BLGNN_ERR_LAUNCH, "gmn_match: cannot raise the dynamic LDS limit");     \
+            declared = lds_bytes;                                                                   \
+        }                                                                                           \
+        hipLaunchKernelGGL((k_gmn_match<CH_>), dim3(blocks), dim3(threads), lds_bytes, s, seg,      \
+                           num_pairs, x, ldx, u, ldu, d, lds_floats);                              \
+    } while (0)
     if (ch <= 1) BLGNN_GMN_LAUNCH(1);
     else if (ch == 2) BLGNN_GMN_LAUNCH(2);
     else if (ch <= 4) BLGNN_GMN_LAUNCH(4);

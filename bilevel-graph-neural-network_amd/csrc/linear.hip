@@ -28,8 +28,71 @@ struct LinearArgs {
     int vec_a, vec_b;      // float4 loads allowed for X / W
 };
 
+template <int ACT>
+__device__ __forceinline__ float act_c(float v, float slope) {
+    if (ACT == BLGNN_ACT_RELU) return fmaxf(v, 0.f);
+    if (ACT == BLGNN_ACT_PRELU) return v > 0.f ? v : slope * v;
+    if (ACT == BLGNN_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    if (ACT == BLGNN_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+// One wave's TM x TN accumulator tiles -> y, 32 rows at a time through its private LDS tile.
+template <int ACT, int TM, int TN, int WN>
+__device__ __forceinline__ void store_out(const LinearArgs &A, const f32x16 (&acc)[TM][TN], float *smem,
+                                          int row0, int col0, int wid, int lane) {
+    constexpr int LDO = WN + 4;
+    constexpr int Q = WN / 4;                            // float4 per staged row
+    float *stage = smem + wid * 32 * LDO;
+    const int fi = lane & 31, fh = lane >> 5;
+    const bool vec_out = (A.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(A.y) & 15u) == 0);
+    float bias[TN], slope[TN], scale[TN], shift[TN], rw[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = col0 + 32 * j + fi;
+        const bool in = n < A.N;
+        bias[j] = (in && A.epi.bias) ? A.epi.bias[n] : 0.f;
+        slope[j] = (in && ACT == BLGNN_ACT_PRELU && A.epi.act_param) ? A.epi.act_param[n] : 0.f;
+        scale[j] = (in && A.epi.bn_scale) ? A.epi.bn_scale[n] : 1.f;
+        shift[j] = (in && A.epi.bn_scale && A.epi.bn_shift) ? A.epi.bn_shift[n] : 0.f;
+        rw[j] = (in && A.rowvec_w) ? A.rowvec_w[n] : 0.f;
+    }
+    __syncthreads();                                     // every wave is done reading As / Bs
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = (r & 3) + 8 * (r >> 2) + 4 * fh;          // row inside the 32-row slab
+                const int m = row0 + 32 * i + lr;
+                float v = acc[i][j][r] + bias[j];
+                if (A.rowvec) v = fmaf((m < A.M) ? A.rowvec[m] : 0.f, rw[j], v);
+                v = act_c<ACT>(v, slope[j]);
+                if (A.epi.bn_scale) v = fmaf(v, scale[j], shift[j]);
+                stage[lr * LDO + 32 * j + fi] = v;
+            }
+        // wave-private tile: LDS operations of one wave complete in order, no barrier needed
+#pragma unroll
+        for (int t = lane; t < 32 * Q; t += WAVE) {
+            const int lr = t / Q, c4 = t % Q;
+            const int m = row0 + 32 * i + lr, n = col0 + 4 * c4;
+            if (m >= A.M || n >= A.N) continue;
+            const float4 v = *reinterpret_cast<const float4 *>(stage + lr * LDO + 4 * c4);
+            float *dst = A.y + (int64_t)m * A.ldy + n;
+            if (vec_out && n + 3 < A.N) *reinterpret_cast<float4 *>(dst) = v;
+            else {
+                dst[0] = v.x;
+                if (n + 1 < A.N) dst[1] = v.y;
+                if (n + 2 < A.N) dst[2] = v.z;
+                if (n + 3 < A.N) dst[3] = v.w;
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(256) k_linear(const LinearArgs A) {
+__global__ void __launch_bounds__(256, 2) k_linear(const LinearArgs A) {
     constexpr int LDA = BM + 1;            // As[k][m]: +1 dword -> conflict-free transposed stores
     constexpr int LDB = BN + 4;            // Bs[k][n]: keeps 16 B alignment for b128 stores
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -40,8 +103,13 @@ __global__ void __launch_bounds__(256) k_linear(const LinearArgs A) {
     constexpr int B_KSTEP = 256 / B_ROWQ;
     static_assert((BM / WM) * (BN / WN) == 4, "4 wavefronts per workgroup");
 
-    __shared__ float As[BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+    // operand images during the K loop; per-wave 32-row output staging tiles afterwards
+    constexpr int LDO = WN + 4;
+    constexpr int OPND = BK * LDA + 3 + BK * LDB;     // As, pad to 16 B, Bs
+    constexpr int STAGE = 4 * 32 * LDO;
+    __shared__ __attribute__((aligned(16))) float smem[OPND > STAGE ? OPND : STAGE];
+    float *As = smem;
+    float *Bs = smem + ((BK * LDA + 3) & ~3);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
@@ -150,24 +218,16 @@ __global__ void __launch_bounds__(256) k_linear(const LinearArgs A) {
         }
     }
 
-    // epilogue: C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn0 + 32 * j + fi;
-        if (n >= A.N) continue;
-        const float rw = A.rowvec_w ? A.rowvec_w[n] : 0.f;
-        const EpilogueCol epi(A.epi, n, true);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (m >= A.M) continue;
-                float v = acc[i][j][r];
-                if (A.rowvec) v = fmaf(A.rowvec[m], rw, v);
-                A.y[(int64_t)m * A.ldy + n] = epi(v);
-            }
-        }
+    // epilogue.  C/D map of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // The activation switch is hoisted out of the element loop (one code path per activation),
+    // and the tile goes through a wave-private LDS staging area so that global stores are whole
+    // row segments at 16 B per lane (64 scalar stores per lane were store-issue bound).
+    switch (A.epi.act) {
+        case BLGNN_ACT_RELU:    store_out<BLGNN_ACT_RELU, TM, TN, WN>(A, acc, smem, m0 + wm0, n0 + wn0, wid, lane); break;
+        case BLGNN_ACT_PRELU:   store_out<BLGNN_ACT_PRELU, TM, TN, WN>(A, acc, smem, m0 + wm0, n0 + wn0, wid, lane); break;
+        case BLGNN_ACT_SIGMOID: store_out<BLGNN_ACT_SIGMOID, TM, TN, WN>(A, acc, smem, m0 + wm0, n0 + wn0, wid, lane); break;
+        case BLGNN_ACT_TANH:    store_out<BLGNN_ACT_TANH, TM, TN, WN>(A, acc, smem, m0 + wm0, n0 + wn0, wid, lane); break;
+        default:                store_out<BLGNN_ACT_IDENTITY, TM, TN, WN>(A, acc, smem, m0 + wm0, n0 + wn0, wid, lane); break;
     }
 }
 

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes of `python bench.py ...` into profiles/<tag>_pmc_summary.json.
+
+HBM traffic per launch of a kernel = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes: on gfx950
+FETCH_SIZE reports half the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md,
+section HBM); WRITE_SIZE is exact for 16 B/lane stores.  Counters are collected in separate
+passes (FETCH_SIZE and WRITE_SIZE do not fit one pass).
+usage: summarize_pmc.py <tag> <kernel-substring> <dir_fetch> <dir_write> [<dir_sq>]"""
+import collections, csv, glob, json, os, sys
+
+def per_kernel(d, sub):
+    out = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if sub in r["Kernel_Name"]:
+                out[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in out.items()}
+
+tag, sub = sys.argv[1], sys.argv[2]
+res = {"kernel_substring": sub, "counters": {}}
+for d in sys.argv[3:]:
+    for k, (mean, n) in per_kernel(d, sub).items():
+        res["counters"][k] = {"mean_per_launch": mean, "launches": n}
+c = res["counters"]
+if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+    res["hbm_read_bytes_per_launch"] = 2.0 * c["FETCH_SIZE"]["mean_per_launch"] * 1024
+    res["hbm_write_bytes_per_launch"] = c["WRITE_SIZE"]["mean_per_launch"] * 1024
+    res["hbm_bytes_per_launch"] = res["hbm_read_bytes_per_launch"] + res["hbm_write_bytes_per_launch"]
+    res["correction"] = "FETCH_SIZE x2 (gfx950 wide-read undercount), WRITE_SIZE x1, both x1024 (KB)"
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), tag + "_pmc_summary.json")
+json.dump(res, open(path, "w"), indent=1)
+print(json.dumps(res))
