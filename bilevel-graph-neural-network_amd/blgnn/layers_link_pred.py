@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from . import ops
 from .config import FLAGS
-from .layers_util import MLP
+from .layers_util import MLP, act_name
 
 __all__ = ["LinkPred"]
 
@@ -63,10 +63,22 @@ class LinkPred(nn.Module):
         ops.require_device(ins, "ins")
         ids = getattr(batch_data, "_pair_row_ids", None)
         if ids is None:
-            ids = torch.as_tensor(self.pair_row_ids(batch_data)).to(ins.device)
+            host = self.pair_row_ids(batch_data)
+            ids = (torch.as_tensor(np.ascontiguousarray(host[:, 0])).to(ins.device),
+                   torch.as_tensor(np.ascontiguousarray(host[:, 1])).to(ins.device))
             batch_data._pair_row_ids = ids
-        ids1, ids2 = ids[:, 0].contiguous(), ids[:, 1].contiguous()
+        ids1, ids2 = ids
+        mlp = getattr(self, "mlp_concat", None)
         with torch.no_grad():
+            if (self.type == "mlp_concat" and len(mlp.layers) <= 4
+                    and max(mlp.layer_channels) <= 2048 and act_name(mlp.activation) != "prelu"):
+                # fused head: gather + normalise + concat + MLP (+ sigmoid) in one launch
+                pair_preds = ops.link_pred_head(
+                    ins, ids1, ids2, [mlp.weight_kn(i) for i in range(len(mlp.layers))],
+                    [lin.bias for lin in mlp.layers], hidden_act=act_name(mlp.activation),
+                    final_act="identity" if self.multi_label_pred else "sigmoid")
+                batch_data.pair_preds = pair_preds
+                return pair_preds
             cat = ops.pair_gather_normalize(ins, ids1, ids2)
             if self.type == "mlp_concat":
                 pair_preds = self.mlp_concat(

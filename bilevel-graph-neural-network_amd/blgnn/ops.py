@@ -13,7 +13,7 @@ from ._lib import call, ACT_IDS, GAT_GROUP, REDUCE_MEAN, REDUCE_SUM
 __all__ = [
     "CSR", "csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear",
     "gat_conv", "gcn_conv", "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum",
-    "row_degree", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
+    "row_degree", "link_pred_head", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
     "require_device",
 ]
 
@@ -278,6 +278,25 @@ def pair_gather_normalize(z, ids1, ids2, eps=1e-12):
     out = torch.empty((B, 2 * d), dtype=torch.float32, device=z.device)
     call("blgnn_pair_gather_normalize", zp, ldz, _vec(ids1, "ids1", torch.int64, False),
          _vec(ids2, "ids2", torch.int64, False), B, d, float(eps), out.data_ptr(), 2 * d, _stream())
+    return out
+
+
+def link_pred_head(z, ids1, ids2, weights_kn, biases, hidden_act="relu", final_act="identity", eps=1e-12):
+    """normalize + gather + concat + MLP (+ sigmoid) of the pair scorer in one launch.
+    ``weights_kn``: list of [K_l, N_l] row-major tensors; ``biases``: list of [N_l] or None."""
+    import ctypes
+    zp, ldz = _mat(z, "z")
+    B, d, L = ids1.numel(), z.shape[1], len(weights_kn)
+    dims = [2 * d] + [int(w.shape[1]) for w in weights_kn]
+    for l, w in enumerate(weights_kn):
+        if w.shape[0] != dims[l]:
+            raise ValueError("blgnn: link_pred_head layer %d expects %d inputs, weight has %d" % (l, dims[l], w.shape[0]))
+    out = torch.empty((B, dims[-1]), dtype=torch.float32, device=z.device)
+    wp = (ctypes.c_void_p * L)(*[_vec(w, "w[%d]" % l, optional=False) for l, w in enumerate(weights_kn)])
+    bp = (ctypes.c_void_p * L)(*[_vec(b, "b[%d]" % l) for l, b in enumerate(biases)])
+    call("blgnn_link_pred_head", zp, ldz, _vec(ids1, "ids1", torch.int64, False),
+         _vec(ids2, "ids2", torch.int64, False), B, d, float(eps), L, wp, bp, (ctypes.c_int32 * (L + 1))(*dims),
+         _act(hidden_act), _act(final_act), out.data_ptr(), dims[-1], _stream())
     return out
 
 

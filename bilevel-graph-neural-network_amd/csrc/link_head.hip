@@ -1,0 +1,175 @@
+// Fused pair scorer (reference: model/layers_link_pred.py:43-67 with type='mlp_concat'):
+//   out[b] = final_act( MLP( [ z[ids1[b]] / |z[ids1[b]]| , z[ids2[b]] / |z[ids2[b]]| ] ) )
+// One wavefront per pair.  The two embedding rows are gathered with coalesced loads, L2
+// normalised with a wave reduction and parked in the wave's LDS slice; every MLP layer is then
+// lane-per-output: lane o walks the (L2-resident, k-major) weight column o while the input
+// activations are LDS broadcasts.  The MLP of this head is tiny (2D -> 2D/8 -> 2D/64 -> 1 or 3):
+// as separate GEMM launches it is three grids of mostly idle 32x32 MFMA tiles plus a gather
+// kernel plus two index copies; fused it is one short launch.
+#include "common.hpp"
+
+namespace blgnn {
+
+constexpr int HEAD_MAX_LAYERS = 4;
+constexpr int HEAD_MAX_WIDTH = 2048;          // floats per activation buffer per wave
+
+struct HeadArgs {
+    const float *z; int64_t ldz;
+    const int64_t *ids1, *ids2;
+    int32_t B, d;
+    float eps;
+    int32_t num_layers;
+    const float *w[HEAD_MAX_LAYERS];
+    const float *b[HEAD_MAX_LAYERS];
+    int32_t dims[HEAD_MAX_LAYERS + 1];
+    int32_t hidden_act, final_act;
+    float *out; int64_t ldo;
+    int32_t width;                            // LDS floats per buffer
+    int32_t w_in_lds;                         // weights fit the LDS budget
+};
+
+__device__ __forceinline__ bool aligned16_dev(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+__device__ __forceinline__ int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+__global__ void __launch_bounds__(256) k_link_head(const HeadArgs A) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+    float *buf0 = lds + (size_t)wid * 2 * A.width;
+    float *buf1 = buf0 + A.width;
+    // all layer weights staged once per workgroup (k-major, as stored): 33 KB for 256->32->4->1.
+    // Read from L2 instead, every k-step of every pair is a dependent ~600-cycle round trip.
+    float *wl = lds + 4 * 2 * (size_t)A.width;
+    const float *wptr[HEAD_MAX_LAYERS];
+    {
+        int off = 0;
+        for (int l = 0; l < A.num_layers; ++l) {
+            const int cnt = A.dims[l] * A.dims[l + 1];
+            if (A.w_in_lds) {
+                const bool v4 = (cnt % 4 == 0) && aligned16_dev(A.w[l]);
+                if (v4) {                                        // independent 16 B loads, all in flight
+                    const float4 *src = reinterpret_cast<const float4 *>(A.w[l]);
+                    float4 *dst = reinterpret_cast<float4 *>(wl + off);
+#pragma unroll 8
+                    for (int i = threadIdx.x; i < cnt / 4; i += 256) dst[i] = src[i];
+                } else {
+                    for (int i = threadIdx.x; i < cnt; i += blockDim.x) wl[off + i] = A.w[l][i];
+                }
+                wptr[l] = wl + off;
+            } else {
+                wptr[l] = A.w[l];
+            }
+            off += (cnt + 3) & ~3;
+        }
+    }
+    __syncthreads();
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int wave_total = gridDim.x * blockDim.x / WAVE;
+    for (int pair = wave_global; pair < A.B; pair += wave_total) {
+        // gather + normalise (model/layers_link_pred.py:44,56-61); both rows requested together
+        {
+            const float *z1 = A.z + A.ids1[pair] * A.ldz, *z2 = A.z + A.ids2[pair] * A.ldz;
+            float s1 = 0.f, s2 = 0.f;
+            for (int c = lane; c < A.d; c += WAVE) {
+                const float a = z1[c], b = z2[c];
+                s1 = fmaf(a, a, s1);
+                s2 = fmaf(b, b, s2);
+            }
+            s1 = group_sum(s1, WAVE);
+            s2 = group_sum(s2, WAVE);
+            const float n1 = fmaxf(sqrtf(s1), A.eps), n2 = fmaxf(sqrtf(s2), A.eps);
+            for (int c = lane; c < A.d; c += WAVE) {
+                buf0[c] = z1[c] / n1;
+                buf0[A.d + c] = z2[c] / n2;
+            }
+        }
+        float *in = buf0, *outb = buf1;
+        for (int l = 0; l < A.num_layers; ++l) {
+            const int K = A.dims[l], N = A.dims[l + 1];
+            const bool last = l == A.num_layers - 1;
+            const int act = last ? A.final_act : A.hidden_act;
+            const float *W = wptr[l];
+            // lanes = (output o, K-part): narrow layers split K over the idle lanes
+            const int Np = N >= WAVE ? WAVE : pow2ceil(N);
+            const int P = WAVE / Np;
+            const int oo = lane % Np, part = lane / Np;
+            for (int o0 = 0; o0 < N; o0 += Np) {
+                const int o = o0 + oo;
+                const bool live = o < N;
+                float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+                int k = part;
+                for (; k + 3 * P < K; k += 4 * P) {                 // 8 independent LDS reads in flight
+                    const float x0 = in[k], x1 = in[k + P], x2 = in[k + 2 * P], x3 = in[k + 3 * P];
+                    const float w0 = live ? W[(int64_t)k * N + o] : 0.f;
+                    const float w1 = live ? W[(int64_t)(k + P) * N + o] : 0.f;
+                    const float w2 = live ? W[(int64_t)(k + 2 * P) * N + o] : 0.f;
+                    const float w3 = live ? W[(int64_t)(k + 3 * P) * N + o] : 0.f;
+                    acc0 = fmaf(x0, w0, acc0);
+                    acc1 = fmaf(x1, w1, acc1);
+                    acc2 = fmaf(x2, w2, acc2);
+                    acc3 = fmaf(x3, w3, acc3);
+                }
+                for (; k < K; k += P) acc0 = fmaf(in[k], live ? W[(int64_t)k * N + o] : 0.f, acc0);
+                acc0 += acc2;
+                acc1 += acc3;
+                float acc = acc0 + acc1;
+                for (int off = Np; off < WAVE; off <<= 1) acc += __shfl_xor(acc, off, WAVE);
+                if (live && part == 0) {
+                    const float v = apply_act(acc + (A.b[l] ? A.b[l][o] : 0.f), act, 0.f);
+                    if (last) A.out[(int64_t)pair * A.ldo + o] = v;
+                    else outb[o] = v;
+                }
+            }
+            float *t = in; in = outb; outb = t;
+        }
+    }
+}
+
+}  // namespace blgnn
+
+using namespace blgnn;
+
+extern "C" int blgnn_link_pred_head(const float *z, int64_t ldz, const int64_t *ids1, const int64_t *ids2,
+                                    int32_t B, int32_t d, float eps, int32_t num_layers,
+                                    const float *const *w_host, const float *const *b_host,
+                                    const int32_t *dims_host, int32_t hidden_act, int32_t final_act,
+                                    float *out, int64_t ldo, void *stream) {
+    BLGNN_CHECK_ARG(B >= 0 && d > 0, "link_pred_head: bad sizes");
+    if (B == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(z && ids1 && ids2 && out && w_host && b_host && dims_host, "link_pred_head: null pointer");
+    BLGNN_CHECK_ARG(num_layers >= 1 && num_layers <= HEAD_MAX_LAYERS, "link_pred_head: 1..4 layers");
+    BLGNN_CHECK_ARG(dims_host[0] == 2 * d, "link_pred_head: dims[0] must be 2*d");
+    BLGNN_CHECK_ARG(ldz >= d && ldo >= dims_host[num_layers], "link_pred_head: leading dimension too small");
+    BLGNN_CHECK_ARG(hidden_act >= 0 && hidden_act <= BLGNN_ACT_TANH && hidden_act != BLGNN_ACT_PRELU &&
+                    final_act >= 0 && final_act <= BLGNN_ACT_TANH && final_act != BLGNN_ACT_PRELU,
+                    "link_pred_head: bad activation id");
+    HeadArgs A = {};
+    int width = 0;
+    for (int l = 0; l <= num_layers; ++l) {
+        BLGNN_CHECK_ARG(dims_host[l] > 0, "link_pred_head: bad layer width");
+        A.dims[l] = dims_host[l];
+        if (l < num_layers) {
+            BLGNN_CHECK_ARG(w_host[l], "link_pred_head: null weight");
+            A.w[l] = w_host[l]; A.b[l] = b_host[l];
+            width = dims_host[l] > width ? dims_host[l] : width;
+        }
+    }
+    width = (width + 3) & ~3;
+    if (width > HEAD_MAX_WIDTH)
+        return fail(BLGNN_ERR_UNSUPPORTED, "link_pred_head: layer width %d > %d; use pair_gather_normalize + linear",
+                    width, HEAD_MAX_WIDTH);
+    A.z = z; A.ldz = ldz; A.ids1 = ids1; A.ids2 = ids2; A.B = B; A.d = d; A.eps = eps;
+    A.num_layers = num_layers; A.hidden_act = hidden_act; A.final_act = final_act;
+    A.out = out; A.ldo = ldo; A.width = width;
+    size_t wfloats = 0;
+    for (int l = 0; l < num_layers; ++l) wfloats += ((size_t)dims_host[l] * dims_host[l + 1] + 3) & ~(size_t)3;
+    const size_t act_bytes = sizeof(float) * 4 * 2 * (size_t)width;
+    A.w_in_lds = (act_bytes + wfloats * sizeof(float)) <= 60 * 1024;
+    const size_t bytes = act_bytes + (A.w_in_lds ? wfloats * sizeof(float) : 0);
+    // one pair per wavefront whenever the batch allows it: a pair is a chain of dependent
+    // latencies (ids -> rows -> three layers), so pairs must run side by side, not in sequence
+    int64_t blocks = ((int64_t)B + 3) / 4;
+    if (blocks > 256 * 4) blocks = 256 * 4;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_link_head, dim3((unsigned)blocks), dim3(256), bytes, (hipStream_t)stream, A);
+    return launch_status("link_pred_head");
+}

@@ -208,6 +208,20 @@ int blgnn_pair_gather_normalize(const float *z, int64_t ldz, const int64_t *ids1
                                 const int64_t *ids2, int32_t B, int32_t d,
                                 float eps, float *out, int64_t ldo, void *stream);
 
+/* The whole mlp_concat pair scorer in one launch: model/layers_link_pred.py:43-67.
+ *   out[b] = final_act( MLP( [normalize(z[ids1[b]]), normalize(z[ids2[b]])] ) )
+ * MLP = num_layers (<= 4) Linear layers, hidden layers followed by hidden_act
+ * (model/layers_util.py:44-57, bn=False as LinkPred builds it).  w_host / b_host are HOST
+ * arrays of device pointers (w[l] is [dims[l], dims[l+1]] row-major, i.e. nn.Linear weights
+ * transposed; b[l] nullable); dims_host = {2*d, h1, ..., out}.  Widths above 2048 return
+ * BLGNN_ERR_UNSUPPORTED (use blgnn_pair_gather_normalize + blgnn_linear). */
+int blgnn_link_pred_head(const float *z, int64_t ldz, const int64_t *ids1,
+                         const int64_t *ids2, int32_t B, int32_t d, float eps,
+                         int32_t num_layers, const float *const *w_host,
+                         const float *const *b_host, const int32_t *dims_host,
+                         int32_t hidden_act, int32_t final_act, float *out,
+                         int64_t ldo, void *stream);
+
 /* y[i] = x[i] / max(|x[i]|_2, eps): model/layers.py:60-61. */
 int blgnn_l2_normalize_rows(const float *x, int64_t ldx, float *y, int64_t ldy,
                             int32_t n, int32_t d, float eps, void *stream);

@@ -135,6 +135,14 @@ def pair_gather_normalize(z, ids1, ids2, eps=1e-12):
     return torch.cat([zn[ids1], zn[ids2]], dim=1)
 
 
+def link_pred_head(z, ids1, ids2, weights_kn, biases, hidden_act="relu", final_act="identity", eps=1e-12):
+    v = pair_gather_normalize(z, ids1, ids2, eps)
+    for i, (w, b) in enumerate(zip(weights_kn, biases)):
+        v = v @ w + (b if b is not None else 0)
+        v = oracle.apply_act(v, hidden_act if i < len(weights_kn) - 1 else final_act)
+    return v
+
+
 def l2_normalize_rows(x, eps=1e-12, out=None):
     return _put(out, oracle.l2_normalize(x, eps))
 
@@ -150,7 +158,7 @@ def require_device(t, name="tensor"):
 
 NAMES = ["csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear", "gin_layer",
          "gin_layer_supported", "gat_conv", "gcn_conv",
-         "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum", "row_degree", "pair_gather_normalize",
+         "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum", "row_degree", "pair_gather_normalize", "link_pred_head",
          "l2_normalize_rows", "scatter_rows", "require_device"]
 
 

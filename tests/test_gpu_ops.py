@@ -291,6 +291,26 @@ def test_pair_gather_and_normalize(device):
     assert max_err(ops.l2_normalize_rows(z.to(device)), zn) < TOL
 
 
+@pytest.mark.parametrize("d,dims,final", [(128, [32, 4, 1], "sigmoid"), (64, [16, 2, 3], "identity"),
+                                          (320, [80, 10, 1], "sigmoid"), (50, [7], "identity")])
+def test_link_pred_head_fused(device, d, dims, final):
+    g = torch.Generator().manual_seed(d)
+    z = torch.randn(300, d, generator=g)
+    z[11] = 0.0
+    ids = torch.randint(0, 300, (1000, 2), generator=g)
+    ids[0, 1] = 11
+    widths = [2 * d] + dims
+    lins = [(torch.randn(widths[i + 1], widths[i], generator=g) / widths[i] ** 0.5,
+             torch.randn(widths[i + 1], generator=g) * 0.1) for i in range(len(dims))]
+    ref = oracle.link_pred(z.double(), ids[:, 0], ids[:, 1], [(w.double(), b.double()) for w, b in lins],
+                           "mlp_concat", multi_label_pred=(final == "identity"))
+    dv = lambda t: t.to(device)
+    got = ops.link_pred_head(dv(z), dv(ids[:, 0].contiguous()), dv(ids[:, 1].contiguous()),
+                             [dv(w.t().contiguous()) for w, _ in lins], [dv(b) for _, b in lins],
+                             hidden_act="relu", final_act=final)
+    assert got.shape == ref.shape and max_err(got, ref) < TOL
+
+
 def test_errors_are_loud(device):
     with pytest.raises(RuntimeError):
         ops.linear(torch.randn(4, 4), torch.randn(4, 4))          # CPU tensors: no fallback
