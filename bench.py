@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the d=256 SpMM/readout micro-roofline")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="profiling aid: build rank 0's share of an N-GPU run on one GPU (no collective)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel eagerly instead of replaying captured HIP graphs")
     return ap.parse_args()
@@ -132,7 +134,10 @@ def main():
     from blgnn.batch import BatchData
     from blgnn.forward import all_molecule_pairs
 
-    ds, flags, data, model, sharded = build_workload(rank, world, device)
+    if args.emulate_world > 1 and world == 1:
+        ds, flags, data, model, sharded = build_workload(0, args.emulate_world, device)
+    else:
+        ds, flags, data, model, sharded = build_workload(rank, world, device)
     k = flags.last_lower_lyr_num
     lower_layers = list(model.layers[:k + 1])
     upper_layers = list(model.layers[k + 1:-1])          # LoadInteraction, GAT x3, LinkPred (no Loss)

@@ -186,6 +186,24 @@ def test_gat_conv(device, group, din, d):
     assert max_err(got, ref) < TOL
 
 
+@pytest.mark.parametrize("d", [64, 128, 320])
+def test_convs_on_large_high_degree_graph(device, d):
+    """5000 rows with mean degree 24 and a heavy tail: the shape of an 8-GPU interaction level"""
+    n = 5000
+    ei = rand_graph(n, 24, 31, self_loops=True, isolated=7)
+    x = torch.randn(n, d)
+    W, att, b = torch.randn(d, d) / d ** 0.5, torch.randn(1, 1, 2 * d) / d ** 0.5, torch.randn(d) * 0.1
+    csr = ops.csr_from_edge_index(ei.to(device), n)
+    dv = lambda t: t.to(device)
+    for group in ("src", "dst"):
+        ref = oracle.gat_conv(x.double(), ei, W.double(), att.double(), b.double(), group)
+        assert max_err(ops.gat_conv(csr, dv(x), dv(W), dv(att), dv(b), group=group), ref) < TOL
+    ref = oracle.gcn_conv(x.double(), ei, W.double(), b.double())
+    assert max_err(ops.gcn_conv(csr, dv(x), dv(W), dv(b)), ref) < TOL
+    ref = oracle.scatter_add(x[ei[1]].double(), ei[0], n) + x.double()
+    assert max_err(ops.spmm_sum(csr, dv(x), 1.0, False), ref) < TOL
+
+
 def test_gat_conv_molecules_and_accumulate(device):
     ei, _, n = molecule_graph(30, 3)
     d = 64
