@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="profiling aid: build rank 0's share of an N-GPU run on one GPU (no collective)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="replay the lower and upper graphs of a step back to back on one stream")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel eagerly instead of replaying captured HIP graphs")
     return ap.parse_args()
@@ -168,63 +170,20 @@ def main():
                                               4.0 * x.shape[0] * (x.shape[1] + w1.shape[1]) + 4.0 * csr.nnz + 4.0 * (csr.n + 1)),
         lambda *a, **kw: True)
 
-    def lower_part():
-        with torch.no_grad():
-            model.acts = [lower_batch.merge_data['merge'].x]
-            for layer in lower_layers:
-                model.acts.append(layer(model.acts[-1], lower_batch, model))
-            return model.acts[-1]                      # pooled rows of this rank's drugs
-
-    def exchange(pooled):
-        if world > 1:                                  # the one collective of the path
-            sharded.gather_init_x(pooled, out=graph.init_x)
-
-    def upper_part(i):
-        with torch.no_grad():
-            b = upper_batches[i % n_batches]
-            model.acts = [b.merge_data['merge'].x]
-            for layer in upper_layers:
-                model.acts.append(layer(model.acts[-1], b, model))
-            return model.acts[-1]
-
-    def step(i):
-        exchange(lower_part())
-        return upper_part(i)
-
-    # The forward is ~40 short launches: captured into HIP graphs (launch-bound inner loops
-    # belong in graphs) and replayed in the timed region.  N = 1: one graph per distinct pair
-    # batch holds the whole forward.  N > 1: the RCCL all-gather stays outside capture -- one
-    # graph for the lower level, the collective, one graph per pair batch for the upper level.
-    use_graph = not args.no_graph
-    for i in range(max(args.warmup, n_batches)):       # every batch once: host->device id copies
-        step(i)                                        # and CSR builds must not fall into a capture
-    torch.cuda.synchronize()
-    g_lower, g_upper, pooled_static, outs = None, [], None, []
-    if use_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            if world > 1:
-                g_lower = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_lower, stream=side):
-                    pooled_static = lower_part()
-            for i in range(n_batches):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
-                    outs.append(upper_part(i) if world > 1 else step(i))
-                g_upper.append(g)
-        torch.cuda.current_stream().wait_stream(side)
-
-    def replay(i):
-        if world > 1:
-            g_lower.replay()
-            exchange(pooled_static)
-        g_upper[i % n_batches].replay()
-        return outs[i % n_batches]
-
-    run = replay if use_graph else step
+    # The forward is ~35 short launches: captured into HIP graphs and replayed, and consecutive
+    # forwards are software-pipelined over two HIP streams (blgnn/engine.py): the molecular
+    # sweep [+ RCCL all-gather, kept outside capture] of step k+1 overlaps the interaction-level
+    # pass + pair scorer of step k.  --no-graph / --no-overlap switch either off.
+    from blgnn.engine import BiLevelEngine
+    engine = BiLevelEngine(model, lower_batch, upper_batches, graph, sharded=sharded, world_size=world,
+                           use_graph=not args.no_graph, overlap=not args.no_overlap)
+    use_graph = engine.use_graph
+    engine.capture()
+    step = engine.eager_step
+    run = engine.step
     for i in range(args.warmup):
         run(i)
+    engine.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -233,7 +192,7 @@ def main():
     timer.enabled = not use_graph
     for i in range(args.steps):
         preds = run(i)
-    torch.cuda.synchronize()
+    engine.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -279,6 +238,7 @@ def main():
                        "drugs_per_gpu": DRUGS_PER_GPU, "atoms_per_gpu": Nn, "mol_edges_per_gpu": nnz,
                        "interaction_pairs": int(len(ds.pair_gids)), "d": D,
                        "pairs_per_step_per_gpu": BATCH_PAIRS, "hip_graph": bool(use_graph),
+                       "two_stream_overlap": bool(engine.overlap),
                        "parallelism": "molecule/pair shards x%d + all-gather(pooled)" % world},
             "roofline": {"kernel": "k_gin_layer (fused GIN layer: CSR gather + 2 fp32-MFMA GEMMs + act/BN)",
                          "bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
