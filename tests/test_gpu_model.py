@@ -187,3 +187,24 @@ def test_engine_graph_replay_and_two_stream_overlap_match_eager(device):
         got = [o.clone() for o in outs[-3:]]
         for k, o in zip(range(4, 7), got):
             assert torch.equal(o, refs[k % 3]), (overlap, k)
+
+
+@pytest.mark.parametrize("node_aggr", ["avg_pool", "deepsets", "gmn_aggr"])
+def test_readout_styles_forward(device, node_aggr):
+    """single-scale mean, DeepSets and the gated GMN aggregator (model/layers_aggregation.py:45-95)"""
+    ds = blgnn.make_synthetic(40, 200, seed=12, device=device)
+    flags = blgnn.make_flags("lower_level_gnn", lower_level_gnn_type="gin", D_lower=64, device=device,
+                             node_aggr=node_aggr)
+    model, data = build(flags, ds, seed=4)
+    specs = layer_specs(flags)
+    bd = blgnn.BatchData(_pairs(ds, 20), ds, is_train=False)
+    ids = torch.as_tensor(np.vectorize(bd.merge_data['gids_to_batch_ind'].get)(bd.batch_gids))
+    of = oracle_flags(flags, ds)
+    sd32 = calibrate_bn(model, specs, plain_batch(bd, ds, torch.float32, with_pairs=ids), of)
+    sd = {n: (v.double() if v.is_floating_point() else v) for n, v in sd32.items()}
+    acts = oracle.run_layers(specs, sd, plain_batch(bd, ds, torch.float64, with_pairs=ids), of)
+    model.acts = [bd.merge_data['merge'].x]
+    for layer in model.layers[:-1]:
+        model.acts.append(layer(model.acts[-1], bd, model))
+    for got, ref in zip(model.acts[1:], acts[1:]):
+        assert max_err(got, ref) < TOL
