@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="profiling aid: build rank 0's share of an N-GPU run on one GPU (no collective)")
+    ap.add_argument("--fuse-lower", action="store_true",
+                    help="run the lower level as ONE launch (blgnn_gin_stack) instead of one per GIN layer")
     ap.add_argument("--no-overlap", action="store_true",
                     help="replay the lower and upper graphs of a step back to back on one stream")
     ap.add_argument("--no-graph", action="store_true",
@@ -176,7 +178,8 @@ def main():
     # pass + pair scorer of step k.  --no-graph / --no-overlap switch either off.
     from blgnn.engine import BiLevelEngine
     engine = BiLevelEngine(model, lower_batch, upper_batches, graph, sharded=sharded, world_size=world,
-                           use_graph=not args.no_graph, overlap=not args.no_overlap)
+                           use_graph=not args.no_graph, overlap=not args.no_overlap,
+                           fuse_lower=args.fuse_lower)
     use_graph = engine.use_graph
     engine.capture()
     step = engine.eager_step
@@ -239,6 +242,7 @@ def main():
                        "interaction_pairs": int(len(ds.pair_gids)), "d": D,
                        "pairs_per_step_per_gpu": BATCH_PAIRS, "hip_graph": bool(use_graph),
                        "two_stream_overlap": bool(engine.overlap),
+                       "fused_lower_stack": engine.fused is not None,
                        "parallelism": "molecule/pair shards x%d + all-gather(pooled)" % world},
             "roofline": {"kernel": "k_gin_layer (fused GIN layer: CSR gather + 2 fp32-MFMA GEMMs + act/BN)",
                          "bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -14,14 +14,107 @@ graph's ``init_x``), ``exchange`` = the all-gather that replaces those row write
 ranks, ``upper`` = the higher-level layers + LinkPred on one edge-pair batch.
 """
 
+import numpy as np
 import torch
 
-__all__ = ["BiLevelEngine"]
+from . import ops
+from .batch import BatchData
+from .layers import NodeEmbedding
+from .layers_aggregation import NodeAggregationPairs, _SegmentPool
+from .layers_util import act_name, bn_affine, prelu_slopes
+
+__all__ = ["BiLevelEngine", "FusedLowerStack"]
+
+TILE_ROWS = 64
+
+
+class FusedLowerStack(object):
+    """The lower level (GIN x L + avg/sum readout) as ONE launch over tiles of whole molecules
+    (``blgnn_gin_stack``), plus the per-layer path for the few molecules larger than a tile.
+    Pooled rows are written straight into the interaction graph's ``init_x``.
+
+    Opt-in (``BiLevelEngine(fuse_lower=True)``): with the feature transform on the fp32 matrix
+    cores the stack is MFMA-bound either way, and whole-molecule tiles waste ~22 % of the MFMA
+    rows on padding and admit only two workgroups per CU, so it measures 228 us against
+    5 x 44 us for the per-layer kernels on the DrugBank-shape batch.  It
+    removes 4/5 of the activation traffic and will pay once the transform is faster."""
+
+    @staticmethod
+    def supported(lower_layers, flags):
+        convs, agg = lower_layers[:-1], lower_layers[-1]
+        if not convs or len(convs) > 8 or 'gmn' in flags.model:
+            return False
+        if not isinstance(agg, NodeAggregationPairs) or not isinstance(agg.agg_func, _SegmentPool):
+            return False
+        n = convs[0].out_dim
+        for i, c in enumerate(convs):
+            if not isinstance(c, NodeEmbedding) or c.type != 'gin' or c.normalize or c.higher_level:
+                return False
+            if c.out_dim != n or act_name(c.act) not in ("relu", "identity", "prelu"):
+                return False
+            if (c.bn and c.bn.training) or c.conv.nn[0].in_features % 4 != 0:
+                return False
+            if i > 0 and c.conv.nn[0].in_features != n:
+                return False
+        return n in (64, 128, 256) and convs[0].conv.nn[0].in_features <= 256
+
+    def __init__(self, lower_layers, dataset, gids):
+        self.convs, self.agg = lower_layers[:-1], lower_layers[-1]
+        self.layers_all = lower_layers
+        sizes = dataset.molecules.sizes[[dataset.molecules.gid_to_pos[g] for g in gids]]
+        small = [g for g, n in zip(gids, sizes) if n <= TILE_ROWS]
+        large = [g for g, n in zip(gids, sizes) if n > TILE_ROWS]
+        self.small = self._batch(small, dataset)
+        self.large = self._batch(large, dataset)
+        self.n = self.convs[0].out_dim
+        L = len(self.convs)
+        self.pool_cols = [l * self.n for l in range(L)] if self.agg.concat_multi_scale \
+            else [-1] * (L - 1) + [0]
+        self.width = self.n * (L if self.agg.concat_multi_scale else 1)
+        if self.small is not None:
+            m = self.small.merge_data['merge']
+            ssz = [b - a for a, b in self.small.merge_data['ind_list']]
+            tiles = ops.molecule_tiles(ssz, TILE_ROWS)
+            self.tile_row = torch.as_tensor(tiles[0]).to(m.x.device)
+            self.tile_mol = torch.as_tensor(tiles[1]).to(m.x.device)
+            self.rows_small = self.small.interaction_rows_of_batch_graphs()
+            m.csr()
+            m.segments()
+
+    @staticmethod
+    def _batch(gids, dataset):
+        if not gids:
+            return None
+        pairs = np.asarray([[gids[i], gids[min(i + 1, len(gids) - 1)]] for i in range(0, len(gids), 2)])
+        return BatchData(pairs, dataset, is_train=False, ignore_pairs=True)
+
+    def _params(self):
+        out = []
+        for c in self.convs:
+            lin1, lin2 = c.conv.nn[0], c.conv.nn[2]
+            scale, shift = bn_affine(c._cache, "bn", c.bn)
+            out.append({
+                "w1": c._cache.get("w1", lambda w: w.t().contiguous(), lin1.weight), "b1": lin1.bias,
+                "w2": c._cache.get("w2", lambda w: w.t().contiguous(), lin2.weight), "b2": lin2.bias,
+                "act": act_name(c.act), "eps": c._cache.get("eps", lambda e: float(e[0]), c.conv.eps),
+                "slope": prelu_slopes(c._cache, "prelu", c.act, c.out_dim), "scale": scale, "shift": shift})
+        return out
+
+    def run(self, model, init_x):
+        with torch.no_grad():
+            if self.small is not None:
+                m = self.small.merge_data['merge']
+                ops.gin_stack(m.csr(), m.x, self.tile_row, self.tile_mol, m.segments(), self._params(),
+                              init_x, self.pool_cols, self.agg.agg_func.kind, row_map=self.rows_small)
+            if self.large is not None:                       # molecules bigger than a tile: per-layer kernels
+                model.acts = [self.large.merge_data['merge'].x]
+                for layer in self.layers_all:
+                    model.acts.append(layer(model.acts[-1], self.large, model))
 
 
 class BiLevelEngine(object):
     def __init__(self, model, lower_batch, upper_batches, graph, sharded=None, world_size=1,
-                 use_graph=True, overlap=True):
+                 use_graph=True, overlap=True, fuse_lower=False):
         from .config import FLAGS
         k = FLAGS.last_lower_lyr_num
         self.model = model
@@ -40,6 +133,15 @@ class BiLevelEngine(object):
         self.g_lower = [None] * self.parities
         self.g_upper = [[None] * self.nb for _ in range(self.parities)]
         self.outs = [[None] * self.nb for _ in range(self.parities)]
+        gids = lower_batch._graph_gids
+        self.fused = None
+        if fuse_lower and FusedLowerStack.supported(self.lower_layers, FLAGS) and \
+                base.shape[1] == self.lower_layers[0].out_dim * (len(self.lower_layers) - 1
+                                                                 if self.lower_layers[-1].concat_multi_scale else 1):
+            self.fused = FusedLowerStack(self.lower_layers, lower_batch.dataset, gids)
+        rows = lower_batch.interaction_rows_of_batch_graphs()
+        self.local_lo = int(rows.min()) if rows.numel() else 0
+        self.local_hi = int(rows.max()) + 1 if rows.numel() else 0
         self.stream_l = torch.cuda.Stream(device=dev) if self.overlap else None
         self.stream_u = torch.cuda.Stream(device=dev) if self.overlap else None
         self.ev_lower = [None] * self.parities
@@ -48,17 +150,21 @@ class BiLevelEngine(object):
 
     # ---- the three pieces of one forward -------------------------------------------------
     def lower(self, parity=0):
+        """-> this rank's pooled rows (a view of init_x: local drugs are a contiguous row range)"""
         self.graph.init_x = self.init_x[parity]
+        if self.fused is not None:
+            self.fused.run(self.model, self.init_x[parity])
+            return self.init_x[parity][self.local_lo:self.local_hi]
         with torch.no_grad():
             m = self.model
             m.acts = [self.lower_batch.merge_data['merge'].x]
             for layer in self.lower_layers:
                 m.acts.append(layer(m.acts[-1], self.lower_batch, m))
-            return m.acts[-1]                                  # pooled rows of this rank's drugs
+            return self.init_x[parity][self.local_lo:self.local_hi]
 
     def exchange(self, pooled, parity=0):
         if self.world > 1:                                     # the one collective of the path
-            self.sharded.gather_init_x(pooled, out=self.init_x[parity])
+            self.sharded.gather_init_x(pooled.clone(), out=self.init_x[parity])
 
     def upper(self, i, parity=0):
         self.graph.init_x = self.init_x[parity]

@@ -13,7 +13,7 @@ from ._lib import call, ACT_IDS, GAT_GROUP, REDUCE_MEAN, REDUCE_SUM
 __all__ = [
     "CSR", "csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear",
     "gat_conv", "gcn_conv", "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum",
-    "row_degree", "link_pred_head", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
+    "row_degree", "link_pred_head", "gin_stack", "molecule_tiles", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
     "require_device",
 ]
 
@@ -144,6 +144,53 @@ def gin_layer(csr, x, w1_kn, b1, w2_kn, b2, eps=0.0, act="identity", act_param=N
          _vec(b2, "b2"), N, float(eps), _act(act), _vec(act_param, "act_param"),
          _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), yp, ldy, _stream())
     return y
+
+
+def molecule_tiles(sizes, max_rows=64):
+    """Greedy packing of CONSECUTIVE molecules into tiles of <= max_rows rows (host side).
+    Returns (tile_row [T+1], tile_mol [T+1]) as int32 numpy arrays, or None when a molecule is
+    larger than a tile (such molecules must go through the per-layer kernels)."""
+    import numpy as np
+    sizes = np.asarray(sizes, dtype=np.int64)
+    if sizes.size == 0 or sizes.max() > max_rows:
+        return None
+    tile_row, tile_mol, fill, row = [0], [0], 0, 0
+    for g, n in enumerate(sizes.tolist()):
+        if fill + n > max_rows:
+            tile_row.append(row); tile_mol.append(g); fill = 0
+        fill += n
+        row += n
+    tile_row.append(row); tile_mol.append(len(sizes))
+    return np.asarray(tile_row, dtype=np.int32), np.asarray(tile_mol, dtype=np.int32)
+
+
+def gin_stack(csr, x0, tile_row, tile_mol, seg, layers, pooled, pool_cols, kind="mean", row_map=None,
+              y_last=None):
+    """L stacked GIN layers + per-layer readout in one launch (include/blgnn.h: blgnn_gin_stack).
+    ``layers``: list of dicts with w1 [K,N], b1, w2 [N,N], b2, act (name), eps, and optional
+    slope / scale / shift; ``pool_cols[l]`` = column offset in ``pooled`` or -1."""
+    import ctypes
+    xp, ldx0 = _mat(x0, "x0")
+    K0 = x0.shape[1]
+    L = len(layers)
+    N = int(layers[0]["w1"].shape[1])
+    T = tile_row.numel() - 1
+
+    def table(key, required=False):
+        return (ctypes.c_void_p * L)(*[_vec(lay.get(key), key, optional=not required) for lay in layers])
+
+    pp, ldp = _mat(pooled, "pooled") if pooled is not None else (None, 0)
+    yp, ldy = _mat(y_last, "y_last") if y_last is not None else (None, 0)
+    call("blgnn_gin_stack", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, xp, ldx0, K0, N, T,
+         _vec(tile_row, "tile_row", torch.int32, False), _vec(tile_mol, "tile_mol", torch.int32, False),
+         _vec(seg, "seg", torch.int32, False), L, table("w1", True), table("b1"), table("w2", True),
+         table("b2"), table("slope"), table("scale"), table("shift"),
+         (ctypes.c_int32 * L)(*[_act(lay["act"]) for lay in layers]),
+         (ctypes.c_float * L)(*[float(lay.get("eps", 0.0)) for lay in layers]),
+         (ctypes.c_int32 * L)(*[int(c) for c in pool_cols]),
+         REDUCE_MEAN if kind == "mean" else REDUCE_SUM, pp, ldp,
+         _vec(row_map, "row_map", torch.int32), yp, ldy, _stream())
+    return pooled
 
 
 def linear(x, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn_shift=None,

@@ -109,6 +109,32 @@ int blgnn_gin_layer(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                     const float *act_param, const float *bn_scale,
                     const float *bn_shift, float *y, int64_t ldy, void *stream);
 
+/* The whole lower level in ONE launch: num_layers (<= 8) stacked GIN NodeEmbedding layers
+ * (model/layers.py:26-31,51-57) + the node -> graph readout of every layer that is pooled
+ * (model/layers_aggregation.py:27-42, multi-scale concat = one column slice per layer).
+ * Works on tiles made of WHOLE molecules (<= 64 rows each): tile_row[T+1] / tile_mol[T+1]
+ * give the first row / first molecule of every tile, seg[G+1] the molecule row offsets; a
+ * molecule's neighbours are then inside its tile at every depth and the layers run out of
+ * LDS back to back.  Layer l: weights w1 [K_l,N], w2 [N,N] (K_0 = K0, K_l = N), biases,
+ * act id (applied after both linears), eps, eval-BN affine (scale/shift nullable), PReLU
+ * slopes (nullable), pool_col = column offset of its pooled rows in `pooled` or -1.
+ * All *_host arguments are HOST arrays indexed by layer (device pointers / values).
+ * pooled[row_map ? row_map[g] : g][pool_col + 0..N) = mean/sum over molecule g;
+ * y_last (nullable) receives the last layer's activations [rows, N].
+ * N in {64,128,256}, K0 % 4 == 0, K0 <= 256, else BLGNN_ERR_UNSUPPORTED. */
+int blgnn_gin_stack(const int32_t *rowptr, const int32_t *col, int64_t nnz,
+                    const float *x0, int64_t ldx0, int32_t K0, int32_t N,
+                    int32_t num_tiles, const int32_t *tile_row,
+                    const int32_t *tile_mol, const int32_t *seg,
+                    int32_t num_layers, const float *const *w1_host,
+                    const float *const *b1_host, const float *const *w2_host,
+                    const float *const *b2_host, const float *const *slope_host,
+                    const float *const *scale_host, const float *const *shift_host,
+                    const int32_t *act_host, const float *eps_host,
+                    const int32_t *pool_col_host, int32_t reduce_kind, float *pooled,
+                    int64_t ldp, const int32_t *row_map, float *y_last, int64_t ldy,
+                    void *stream);
+
 /* GCNConv: model/layers.py:23,52 (formula documented at
  * model/layers_meta.py:128-148).  Step 1: dis[i] = (1 + sum_{j!=i} w_ij)^-1/2
  * (inf -> 0).  */

@@ -177,10 +177,18 @@ def test_engine_graph_replay_and_two_stream_overlap_match_eager(device):
     rng = np.random.default_rng(3)
     uppers = [blgnn.BatchData(ds.pair_gids[rng.choice(len(ds.pair_gids), 96, replace=False)], ds, is_train=False)
               for _ in range(3)]
-    ref_engine = BiLevelEngine(model, lower, uppers, g, use_graph=False)
+    plain_engine = BiLevelEngine(model, lower, uppers, g, use_graph=False, fuse_lower=False)
+    plain = [plain_engine.eager_step(i).clone() for i in range(3)]
+    init_plain = g.init_x.clone()
+    ref_engine = BiLevelEngine(model, lower, uppers, g, use_graph=False, fuse_lower=True)
+    assert ref_engine.fused is not None and ref_engine.fused.large is not None      # both paths exercised
     refs = [ref_engine.eager_step(i).clone() for i in range(3)]
+    # one-launch lower stack (whole-molecule tiles) == layer-by-layer kernels, to rounding
+    assert max_err(g.init_x, init_plain) < TOL
+    for a, b in zip(refs, plain):
+        assert max_err(a, b) < TOL
     for overlap in (False, True):
-        eng = BiLevelEngine(model, lower, uppers, g, use_graph=True, overlap=overlap)
+        eng = BiLevelEngine(model, lower, uppers, g, use_graph=True, overlap=overlap, fuse_lower=True)
         eng.capture()
         outs = [eng.step(i) for i in range(7)]          # > 2 * parities: buffers are reused
         eng.synchronize()

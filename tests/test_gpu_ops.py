@@ -162,6 +162,46 @@ def test_gin_layer_fused(device, K, N, act):
     assert torch.equal(wide[:, 4:4 + N], got) and float(wide[:, :4].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("K0,N,L", [(52, 128, 5), (52, 64, 3), (40, 256, 2), (128, 128, 1)])
+def test_gin_stack_fused_lower_level(device, K0, N, L):
+    """L GIN layers + multi-scale mean readout in one launch == layer-by-layer oracle"""
+    ds = blgnn.make_synthetic(90, 10, seed=K0 + N, device="cpu")
+    keep = [g for g in ds.molecules.gids if ds.molecules.sizes[ds.molecules.gid_to_pos[g]] <= 64]
+    merged = ds.molecules.merge(keep)
+    m = merged["merge"]
+    n, G = m.x.shape[0], len(keep)
+    sizes = np.asarray([b - a for a, b in merged["ind_list"]])
+    g = torch.Generator().manual_seed(L)
+    x0 = torch.randn(n, K0, generator=g)
+    layers, x64, pooled_ref = [], x0.double(), []
+    for l in range(L):
+        K = K0 if l == 0 else N
+        act = "relu" if l < L - 1 else "identity"
+        w1, b1 = torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g) * 0.1
+        w2, b2 = torch.randn(N, N, generator=g) / N ** 0.5, torch.randn(N, generator=g) * 0.1
+        scale, shift = torch.rand(N, generator=g) * 0.5 + 0.25, torch.randn(N, generator=g) * 0.1
+        D = lambda t: t.double()
+        x64 = oracle.apply_act(oracle.gin_conv(x64, m.edge_index, D(w1), D(b1), D(w2), D(b2), act), act) * D(scale) + D(shift)
+        pooled_ref.append(oracle.scatter_mean(x64, m.batch, G))
+        dv = lambda t: t.contiguous().to(device)
+        layers.append({"w1": dv(w1.t()), "b1": dv(b1), "w2": dv(w2.t()), "b2": dv(b2), "act": act, "eps": 0.0,
+                       "scale": dv(scale), "shift": dv(shift)})
+    tiles = ops.molecule_tiles(sizes, 64)
+    assert tiles is not None and int(np.diff(tiles[0]).max()) <= 64
+    csr = ops.csr_from_edge_index(m.edge_index.to(device), n)
+    seg = torch.as_tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=device)
+    pooled = torch.zeros(G + 3, L * N + 8, device=device)
+    rows = torch.arange(G, dtype=torch.int32, device=device).flip(0) + 3           # scattered output rows
+    y_last = torch.empty(n, N, device=device)
+    ops.gin_stack(csr, x0.to(device), torch.as_tensor(tiles[0], device=device), torch.as_tensor(tiles[1], device=device),
+                  seg, layers, pooled[:, 4:4 + L * N], [l * N for l in range(L)], "mean", row_map=rows, y_last=y_last)
+    ref = torch.cat(pooled_ref, dim=1)
+    assert max_err(pooled[rows.long(), 4:4 + L * N], ref) < TOL
+    assert max_err(y_last, x64) < TOL
+    assert float(pooled[:3].abs().max()) == 0.0 and float(pooled[:, :4].abs().max()) == 0.0
+    assert ops.molecule_tiles([10, 70, 3], 64) is None
+
+
 def test_gin_layer_unsupported_shapes_are_reported(device):
     ei, _, n = molecule_graph(5, 1)
     csr = ops.csr_from_edge_index(ei.to(device), n)
