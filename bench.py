@@ -40,6 +40,7 @@ BATCH_PAIRS = 4096
 D = 128
 SEED = 20200614 + 2
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (same table)
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -55,6 +56,8 @@ def parse():
                     help="profiling aid: build rank 0's share of an N-GPU run on one GPU (no collective)")
     ap.add_argument("--fuse-lower", action="store_true",
                     help="run the lower level as ONE launch (blgnn_gin_stack) instead of one per GIN layer")
+    ap.add_argument("--exact-f32", action="store_true",
+                    help="run the fused GIN layer's transforms on the exact-f32 MFMA path instead of bf16x6")
     ap.add_argument("--no-overlap", action="store_true",
                     help="replay the lower and upper graphs of a step back to back on one stream")
     ap.add_argument("--no-graph", action="store_true",
@@ -88,14 +91,14 @@ class KernelTimer(object):
         return ms, self.work
 
 
-def build_workload(rank, world, device):
+def build_workload(rank, world, device, transform="bf16x6"):
     import blgnn
     from blgnn.dist import ShardedLower
     n_drugs = DRUGS_PER_GPU * world
     ds = blgnn.make_synthetic(n_drugs, PAIRS_PER_DRUGSET * world, shape="drugbank", seed=SEED, device=device)
     flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin",
                              higher_level_gnn_type="gat", D_lower=D, D_higher=D, device=device,
-                             batch_size=BATCH_PAIRS)
+                             batch_size=BATCH_PAIRS, feature_transform=transform)
     blgnn.set_flags(flags)
     torch.manual_seed(SEED)
     data = blgnn.TrainData(ds, device=device)
@@ -138,10 +141,11 @@ def main():
     from blgnn.batch import BatchData
     from blgnn.forward import all_molecule_pairs
 
+    transform = "f32" if args.exact_f32 else "bf16x6"
     if args.emulate_world > 1 and world == 1:
-        ds, flags, data, model, sharded = build_workload(0, args.emulate_world, device)
+        ds, flags, data, model, sharded = build_workload(0, args.emulate_world, device, transform)
     else:
-        ds, flags, data, model, sharded = build_workload(rank, world, device)
+        ds, flags, data, model, sharded = build_workload(rank, world, device, transform)
     k = flags.last_lower_lyr_num
     lower_layers = list(model.layers[:k + 1])
     upper_layers = list(model.layers[k + 1:-1])          # LoadInteraction, GAT x3, LinkPred (no Loss)
@@ -163,14 +167,21 @@ def main():
     Nn = int(lower_batch.merge_data['merge'].x.shape[0])
     nnz = int(lower_batch.merge_data['merge'].edge_index.shape[1])
 
-    # dominant kernel: the fused GIN layer (CSR gather -> LDS -> 2 fp32-MFMA GEMMs -> epilogue)
+    # dominant kernel: the fused GIN layer (CSR gather -> LDS -> 2 matrix-core GEMMs -> epilogue),
+    # bf16x6 variant by default (FLAGS.feature_transform), exact-f32 MFMA variant otherwise
     timer = KernelTimer()
-    real_gin = ops.gin_layer
+    real_gin, real_gin6 = ops.gin_layer, ops.gin_layer_x6
     ops.gin_layer = timer.wrap(
         real_gin,
         lambda csr, x, w1, b1, w2, *a, **kw: (2.0 * x.shape[0] * (w1.shape[0] * w1.shape[1] + w2.shape[0] * w2.shape[1]),
                                               4.0 * x.shape[0] * (x.shape[1] + w1.shape[1]) + 4.0 * csr.nnz + 4.0 * (csr.n + 1)),
         lambda *a, **kw: True)
+    ops.gin_layer_x6 = timer.wrap(
+        real_gin6,
+        lambda csr, x, w1p, b1, w2p, b2, N, *a, **kw: (2.0 * x.shape[0] * (x.shape[1] * N + N * N),
+                                                       4.0 * x.shape[0] * (x.shape[1] + N) + 4.0 * csr.nnz + 4.0 * (csr.n + 1)),
+        lambda *a, **kw: True)
+    x6 = getattr(flags, "feature_transform", "bf16x6") == "bf16x6"
 
     # The forward is ~35 short launches: captured into HIP graphs and replayed, and consecutive
     # forwards are software-pipelined over two HIP streams (blgnn/engine.py): the molecular
@@ -204,8 +215,13 @@ def main():
     if use_graph:
         # HIP events cannot sit inside a replayed graph: the dominant kernel is timed over the
         # same K steps launched eagerly right after the timed region (same inputs, same stream)
+        # A long matmul is queued ahead of every step so that the step's launches wait in the
+        # queue and the events bracket back-to-back execution, not host launch latency.
         timer.enabled = True
+        blk = torch.empty(4096, 8192, device=device)
+        blk_w = torch.empty(8192, 8192, device=device)
         for i in range(args.steps):
+            torch.mm(blk, blk_w)
             step(i)
         torch.cuda.synchronize()
         timer.enabled = False
@@ -216,7 +232,7 @@ def main():
     assert preds.shape == (BATCH_PAIRS, 1) and bool(torch.isfinite(preds).all())
 
     ms, work = timer.result()
-    ops.gin_layer = real_gin
+    ops.gin_layer, ops.gin_layer_x6 = real_gin, real_gin6
     out = None
     if rank == 0:
         value = world * BATCH_PAIRS * args.steps / elapsed
@@ -224,17 +240,30 @@ def main():
         # (profiles/summarize_pmc.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction)
         traffic = None
         try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_gin_layer_pmc_summary.json")))[
-                "hbm_bytes_per_launch"]
+            name = "r01_gin_layer_x6_pmc_summary.json" if x6 else "r01_gin_layer_pmc_summary.json"
+            traffic = json.load(open(os.path.join(ROOT, "profiles", name)))["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         tflops = sum(w[0] for w in work) / (sum(ms) * 1e-3) / 1e12 if ms else 0.0
         alg_gbps = sum(w[1] for w in work) / (sum(ms) * 1e-3) / 1e9 if ms else 0.0
+        # bf16x6: every algorithmic fp32 product is six bf16 MFMA products -> the executed
+        # matrix-core rate is 6x the algorithmic one and is priced against the bf16 dense peak
+        mfma_mult, peak = (6.0, PEAK_BF16_MFMA_TFLOPS) if x6 else (1.0, PEAK_F32_MFMA_TFLOPS)
+        roofline = {
+            "kernel": ("k_gin_layer_x6 (fused GIN layer: CSR gather in LDS + 2 GEMMs as 6 bf16 MFMA products "
+                       "per fp32 product + act/BN)") if x6 else
+                      "k_gin_layer (fused GIN layer: CSR gather in LDS + 2 exact-f32 MFMA GEMMs + act/BN)",
+            "bound": "mfma", "achieved": mfma_mult * tflops, "peak": peak, "unit": "TFLOP/s",
+            "frac": mfma_mult * tflops / peak, "traffic": traffic,
+            "algorithmic_f32_tflops": tflops, "frac_of_f32_mfma_peak": tflops / PEAK_F32_MFMA_TFLOPS,
+            "alg_bytes_per_launch": sum(w[1] for w in work) / max(len(work), 1),
+            "launches": len(ms), "avg_us": 1e3 * sum(ms) / max(len(ms), 1),
+            "alg_hbm_GBps": alg_gbps, "alg_hbm_frac": alg_gbps / PEAK_HBM_GBPS}
         out = {
             "metric": "DDI edge-pairs/sec (bi-level forward)",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (dense transforms as bf16x6 split MFMA, fp32-equivalent)" if x6 else "f32",
             "data": "synthetic",
             "config": {"workload": "DrugBank-shape DDI, lower GIN x5 + upper GAT x3, d=128, "
                                    "batch=4096 edge pairs per GPU (BASELINE configs[1])",
@@ -244,12 +273,7 @@ def main():
                        "two_stream_overlap": bool(engine.overlap),
                        "fused_lower_stack": engine.fused is not None,
                        "parallelism": "molecule/pair shards x%d + all-gather(pooled)" % world},
-            "roofline": {"kernel": "k_gin_layer (fused GIN layer: CSR gather + 2 fp32-MFMA GEMMs + act/BN)",
-                         "bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "alg_bytes_per_launch": sum(w[1] for w in work) / max(len(work), 1),
-                         "launches": len(ms), "avg_us": 1e3 * sum(ms) / max(len(ms), 1),
-                         "alg_hbm_GBps": alg_gbps, "alg_hbm_frac": alg_gbps / PEAK_HBM_GBPS},
+            "roofline": roofline,
         }
         if not args.no_extra:
             out["extra"] = micro_roofline(device)

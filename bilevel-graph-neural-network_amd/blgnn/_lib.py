@@ -34,6 +34,9 @@ SIGNATURES = {
     "blgnn_spmm_sum": [_p, _p, _i64, _p, _p, _i64, _p, _i64, _i32, _i32, _f32, _i32, _p],
     "blgnn_gin_layer": [_p, _p, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _p, _i32, _f32, _i32, _p, _p, _p,
                         _p, _i64, _p],
+    "blgnn_pack_weight_x6": [_p, _i64, _i32, _i32, _p, _p],
+    "blgnn_gin_layer_x6": [_p, _p, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _p, _i32, _f32, _i32, _p, _p, _p,
+                           _p, _i64, _p],
     "blgnn_gin_stack": [_p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p,
                         _p, _p, _p, _i32, _p, _i64, _p, _p, _i64, _p],
     "blgnn_gcn_deg_inv_sqrt": [_p, _p, _p, _i32, _p, _p],
@@ -53,7 +56,7 @@ SIGNATURES = {
     "blgnn_l2_normalize_rows": [_p, _i64, _p, _i64, _i32, _i32, _f32, _p],
     "blgnn_scatter_rows": [_p, _i64, _p, _p, _i64, _i32, _i32, _p],
 }
-LIBRARY_SYMBOLS = ["blgnn_version", "blgnn_last_error", "blgnn_device_count"]
+LIBRARY_SYMBOLS = ["blgnn_version", "blgnn_last_error", "blgnn_device_count", "blgnn_packed_weight_x6_elems"]
 
 _lib = None
 
@@ -80,6 +83,8 @@ def load():
     lib.blgnn_version.restype = ctypes.c_int
     lib.blgnn_last_error.restype = ctypes.c_char_p
     lib.blgnn_device_count.restype = ctypes.c_int
+    lib.blgnn_packed_weight_x6_elems.argtypes = [_i32, _i32]
+    lib.blgnn_packed_weight_x6_elems.restype = ctypes.c_int64
     _lib = lib
     return lib
 

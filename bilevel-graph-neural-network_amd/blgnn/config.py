@@ -64,7 +64,7 @@ def make_flags(model="higher_level_gnn", dataset="drugbank", lower_level_gnn_typ
                higher_level_gnn_type="gat", D_lower=64, D_higher=64,
                lower_level_num_layers=None, higher_level_num_layers=3, batch_size=None,
                device="cuda:0", node_aggr=None, bn=True, gnn_normalize=False,
-               gat_softmax_group="src", d_init=64):
+               gat_softmax_group="src", d_init=64, feature_transform="bf16x6"):
     """Reproduce the flag values and layer list of src/config.py for ``model``.
     Defaults are the reference's (config.py:96,126-131,180,237-238)."""
     if model not in MODELS:
@@ -148,6 +148,10 @@ def make_flags(model="higher_level_gnn", dataset="drugbank", lower_level_gnn_typ
     f.num_negative_samples = 1
     f.pair_interaction = False
     f.gat_softmax_group = gat_softmax_group     # SURVEY section 8c(5); not a reference flag
+    # how the fused GIN layer runs its two dense transforms (not a reference flag):
+    #   "bf16x6": bf16 matrix cores, operands split in three pieces, fp32-equivalent accuracy
+    #   "f32":    exact-f32 MFMA (v_mfma_f32_32x32x2_f32), 2.7x more matrix-core time
+    f.feature_transform = feature_transform
     if last_lower is not None:
         f.last_lower_lyr_num = last_lower
     for i, s in enumerate(layers):

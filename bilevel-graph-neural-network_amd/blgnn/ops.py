@@ -13,7 +13,7 @@ from ._lib import call, ACT_IDS, GAT_GROUP, REDUCE_MEAN, REDUCE_SUM
 __all__ = [
     "CSR", "csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear",
     "gat_conv", "gcn_conv", "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum",
-    "row_degree", "link_pred_head", "gin_stack", "molecule_tiles", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
+    "row_degree", "link_pred_head", "pack_weight_x6", "gin_layer_x6", "gin_layer_x6_supported", "gin_stack", "molecule_tiles", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
     "require_device",
 ]
 
@@ -143,6 +143,35 @@ def gin_layer(csr, x, w1_kn, b1, w2_kn, b2, eps=0.0, act="identity", act_param=N
          _vec(w1_kn, "w1", optional=False), _vec(b1, "b1"), _vec(w2_kn, "w2", optional=False),
          _vec(b2, "b2"), N, float(eps), _act(act), _vec(act_param, "act_param"),
          _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), yp, ldy, _stream())
+    return y
+
+
+def pack_weight_x6(w_kn):
+    """[K, N] fp32 weights -> the three-piece bf16 packing the bf16x6 kernels read."""
+    wp, ldw = _mat(w_kn, "w")
+    K, N = w_kn.shape
+    out = torch.empty(int(_lib.load().blgnn_packed_weight_x6_elems(K, N)), dtype=torch.bfloat16,
+                      device=w_kn.device)
+    call("blgnn_pack_weight_x6", wp, ldw, K, N, out.data_ptr(), _stream())
+    return out
+
+
+def gin_layer_x6_supported(csr, x, K, N):
+    return (N in (128, 256) and K % 4 == 0 and K <= 256 and x.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0 and csr.nnz < 12 * max(csr.n, 1))
+
+
+def gin_layer_x6(csr, x, w1_packed, b1, w2_packed, b2, N, eps=0.0, act="identity", act_param=None,
+                 bn_scale=None, bn_shift=None, out=None):
+    """blgnn_gin_layer with both GEMMs on the bf16 matrix cores at fp32 accuracy (bf16x6)."""
+    xp, ldx = _mat(x, "x")
+    n, K = x.shape
+    y = _out(out, n, N, x)
+    yp, ldy = _mat(y, "out")
+    call("blgnn_gin_layer_x6", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, xp, ldx, n, K,
+         w1_packed.data_ptr(), _vec(b1, "b1"), w2_packed.data_ptr(), _vec(b2, "b2"), N, float(eps), _act(act),
+         _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), yp, ldy,
+         _stream())
     return y
 
 

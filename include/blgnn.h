@@ -109,6 +109,22 @@ int blgnn_gin_layer(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                     const float *act_param, const float *bn_scale,
                     const float *bn_shift, float *y, int64_t ldy, void *stream);
 
+/* Same layer with the two dense transforms on the bf16 matrix cores at fp32 accuracy
+ * ("bf16x6": operands split into three bf16 pieces, six MFMAs per product term, fp32
+ * accumulation; error vs fp64 at or below a sequential fp32 fma chain -- DESIGN.md section 4).
+ * w1_packed / w2_packed come from blgnn_pack_weight_x6 (call once per weight version):
+ * [3 pieces][Kp/8][N][8] bf16 with Kp = K rounded up to 32, blgnn_packed_weight_x6_elems(K, N)
+ * bf16 elements.  N in {128,256}, K % 4 == 0, K <= 256, else BLGNN_ERR_UNSUPPORTED. */
+int64_t blgnn_packed_weight_x6_elems(int32_t K, int32_t N);
+int blgnn_pack_weight_x6(const float *w, int64_t ldw, int32_t K, int32_t N, void *out,
+                         void *stream);
+int blgnn_gin_layer_x6(const int32_t *rowptr, const int32_t *col, int64_t nnz,
+                       const float *x, int64_t ldx, int32_t n, int32_t K,
+                       const void *w1_packed, const float *b1, const void *w2_packed,
+                       const float *b2, int32_t N, float eps, int32_t act,
+                       const float *act_param, const float *bn_scale,
+                       const float *bn_shift, float *y, int64_t ldy, void *stream);
+
 /* The whole lower level in ONE launch: num_layers (<= 8) stacked GIN NodeEmbedding layers
  * (model/layers.py:26-31,51-57) + the node -> graph readout of every layer that is pooled
  * (model/layers_aggregation.py:27-42, multi-scale concat = one column slice per layer).

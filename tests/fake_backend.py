@@ -86,6 +86,10 @@ def gin_layer(csr, x, w1_kn, b1, w2_kn, b2, eps=0.0, act="identity", act_param=N
     return _put(out, _epi(v, act, act_param, bn_scale, bn_shift))
 
 
+def gin_layer_x6_supported(csr, x, K, N):
+    return False                                   # the CPU stand-in has no packed-weight path
+
+
 def gat_conv(csr, x, weight, att, bias, group="src", slope=0.2, act="identity", act_param=None,
              bn_scale=None, bn_shift=None, out=None, accumulate=False):
     v = oracle.gat_conv(x, csr.edge_index, weight, att, bias, group, slope)
@@ -157,7 +161,7 @@ def require_device(t, name="tensor"):
 
 
 NAMES = ["csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear", "gin_layer",
-         "gin_layer_supported", "gat_conv", "gcn_conv",
+         "gin_layer_supported", "gin_layer_x6_supported", "gat_conv", "gcn_conv",
          "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum", "row_degree", "pair_gather_normalize", "link_pred_head",
          "l2_normalize_rows", "scatter_rows", "require_device"]
 

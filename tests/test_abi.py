@@ -15,7 +15,7 @@ def _declared():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(?:int|const\s+char\s*\*)\s*(blgnn_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(?:int64_t|int|const\s+char\s*\*)\s*(blgnn_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
         args = m.group(2).strip()
         n = 0 if args == "void" else len([a for a in args.split(",") if a.strip()])
         out[m.group(1)] = n

@@ -202,6 +202,31 @@ def test_gin_stack_fused_lower_level(device, K0, N, L):
     assert ops.molecule_tiles([10, 70, 3], 64) is None
 
 
+@pytest.mark.parametrize("K,N,act", [(52, 128, "relu"), (128, 128, "relu"), (128, 128, "identity"), (40, 256, "relu"),
+                                     (256, 256, "relu"), (256, 128, "prelu"), (64, 256, "tanh")])
+def test_gin_layer_bf16x6(device, K, N, act):
+    """bf16 three-piece split transform (six MFMAs per product) keeps the fp32 parity bar"""
+    ei, _, n = molecule_graph(37, 23)
+    g = torch.Generator().manual_seed(K * 7 + N)
+    x = torch.randn(n, K, generator=g) * 3.0                       # not just O(1) inputs
+    w1, b1 = torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g) * 0.1
+    w2, b2 = torch.randn(N, N, generator=g) / N ** 0.5, torch.randn(N, generator=g) * 0.1
+    slope, scale, shift = torch.rand(N, generator=g), torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    D = lambda t: t.double()
+    ref = oracle.gin_conv(D(x), ei, D(w1), D(b1), D(w2), D(b2), act, eps=0.25, prelu_weight=D(slope))
+    ref = oracle.apply_act(ref, act, D(slope)) * D(scale) + D(shift)
+    dv = lambda t: t.to(device)
+    csr = ops.csr_from_edge_index(dv(ei), n)
+    assert ops.gin_layer_x6_supported(csr, dv(x), K, N)
+    w1p, w2p = ops.pack_weight_x6(dv(w1.t().contiguous())), ops.pack_weight_x6(dv(w2.t().contiguous()))
+    got = ops.gin_layer_x6(csr, dv(x), w1p, dv(b1), w2p, dv(b2), N, eps=0.25, act=act, act_param=dv(slope),
+                           bn_scale=dv(scale), bn_shift=dv(shift))
+    exact = ops.gin_layer(csr, dv(x), dv(w1.t().contiguous()), dv(b1), dv(w2.t().contiguous()), dv(b2), eps=0.25,
+                          act=act, act_param=dv(slope), bn_scale=dv(scale), bn_shift=dv(shift))
+    e6, e32 = max_err(got, ref), max_err(exact, ref)
+    assert e6 < TOL and e6 < 4 * e32 + 2e-7, (e6, e32)            # as accurate as the exact-f32 MFMA path
+
+
 def test_gin_layer_unsupported_shapes_are_reported(device):
     ei, _, n = molecule_graph(5, 1)
     csr = ops.csr_from_edge_index(ei.to(device), n)
