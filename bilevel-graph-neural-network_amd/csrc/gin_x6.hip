@@ -22,14 +22,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #ifdef X6_STAMP
-__device__ unsigned long long g_x6_stamps[48];
+__device__ unsigned long long g_x6_stamps[16];
 #define XSTAMP(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_x6_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
-#define WSTAMP(k) do { if (blockIdx.x == gridDim.x / 2 && i == 3 && (threadIdx.x == 0 || threadIdx.x == 256)) g_x6_stamps[(threadIdx.x == 0 ? 0 : 16) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define GSTAMP(k) do { if (blockIdx.x == gridDim.x / 2 && t == (int)blockIdx.x + 4 * (int)gridDim.x && threadIdx.x == 256) g_x6_stamps[32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define XSTAMP(i)
-#define WSTAMP(k)
-#define GSTAMP(k)
 #endif
 
 constexpr int XCOLS = 256;       // column indices of a tile kept in LDS (32 rows x mean degree 2.1 = 68)
@@ -167,40 +163,8 @@ __device__ __forceinline__ void gemm_x6(f32x16 (&acc0)[MT][NTW], f32x16 (&acc1)[
     }
 }
 
-// Resident variant (K <= 128, N == 128): all weight fragments of the GEMM sit in registers
-// (4 chunks x 24 VGPRs), requested long before the GEMM starts; as soon as chunk c has been
-// consumed its registers are refilled with chunk c of the NEXT weight matrix, so the second GEMM
-// finds its weights resident too and neither GEMM waits on L2.
-#ifndef X6_RES_OCC
-#define X6_RES_OCC 2
-#endif
-constexpr int RCH = 4;
-#ifndef X6_RLATE
-#define X6_RLATE 2
-#endif
-constexpr int RLATE = X6_RLATE;   // W1 chunks >= RLATE are requested after the gather (register pressure)
-template <int N, int NTW, int MT, int XBM>
-__device__ __forceinline__ void gemm_x6_resident(f32x16 (&acc0)[MT][NTW], f32x16 (&acc1)[MT][NTW], const char *Ap,
-                                                 int sa, int Kp, bf16x8 (&w)[RCH][2][3][NTW],
-                                                 bool refill, wrsrc_t Wnext, int Kp_next, int nload,
-                                                 unsigned lane_off, int fi, int fh) {
-    const char *arow = Ap + fi * sa + fh * 16;
-#pragma unroll
-    for (int c = 0; c < RCH; ++c) {
-        if (c * KC < Kp) mfma_chunk_x6<NTW, MT, XBM>(acc0, acc1, arow, sa, c * KC, w[c]);
-        if (refill && c < nload && c * KC < Kp_next) load_b_x6<N, NTW>(w[c], Wnext, Kp_next, c * KC, lane_off);
-    }
-}
-
-// One kernel, two shapes:
-//  RES = false  one tile per workgroup, weight chunks streamed (any K <= 256, N in {128, 256});
-//  RES = true   persistent workgroups (two per CU) looping over tiles, weights resident in
-//               registers; while the GEMMs of tile t run, the rowptr slice, feature rows and column
-//               indices of tile t+1 are already in flight and the weight registers consumed by
-//               GEMM2 are refilled with W1 for tile t+1, so only the out-of-tile neighbour loads
-//               of the gather still wait on L2.
-template <int N, int LG, int ACT, int XBM, bool RES>
-__global__ void __launch_bounds__(256, XBM == 32 ? (RES ? X6_RES_OCC : 3) : 1) k_gin_layer_x6(const GinX6Args A) {
+template <int N, int LG, int ACT, int XBM>
+__global__ void __launch_bounds__(256, XBM == 32 ? 3 : 1) k_gin_layer_x6(const GinX6Args A) {
     constexpr int NTW = N / 128;                    // 4 waves side by side over N
     constexpr int MT = XBM / 32;
     constexpr int RPW = WAVE / LG;
@@ -208,6 +172,7 @@ __global__ void __launch_bounds__(256, XBM == 32 ? (RES ? X6_RES_OCC : 3) : 1) k
     constexpr int LDO = N + 4;
     constexpr int SH = N * 2 + 16;                  // hidden piece row stride (bytes)
     constexpr int NCV = XCOLS / 256;
+    constexpr int N4 = N / 4;
     extern __shared__ float4 lds4[];
     char *lds = reinterpret_cast<char *>(lds4);
     const int sa = A.Kp * 2 + 16;                   // aggregated piece row stride (bytes)
@@ -233,556 +198,204 @@ __global__ void __launch_bounds__(256, XBM == 32 ? (RES ? X6_RES_OCC : 3) : 1) k
     const bool ok = l < k4n;
     const float4 *__restrict__ X = reinterpret_cast<const float4 *>(A.x);
     const int64_t ldx4 = A.ldx >> 2;
-    const int ntiles = (A.n + XBM - 1) / XBM;
-    constexpr int N4 = N / 4;
+    const int m0 = blockIdx.x * XBM;
     const bool vec_out = (A.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(A.y) & 15u) == 0);
 
     XSTAMP(0);
-    // ---- prologue: requests for the first tile --------------------------------------------------------
-    int tile = blockIdx.x;
-    int rpv = 0, e_lo, ncol_all;
+    // ---- (0) requests: rowptr slice, feature rows, first weight chunk, edge range -> column indices ---------
+    int rpv = 0;
+    if (threadIdx.x <= XBM) {
+        const int r = m0 + threadIdx.x;
+        rpv = A.rowptr[r < A.n ? r : A.n];
+    }
     float4 xin[PASSES];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int row = m0 + (p * 4 + wid) * RPW + sub;
+        xin[p] = (ok && row < A.n) ? X[(int64_t)row * ldx4 + l] : f4_zero();
+    }
+    bf16x8 wfrag[2][3][NTW];
+    load_b_x6<N, NTW>(wfrag, W1, A.Kp, 0, lane_off);
+    const int e_lo = A.rowptr[m0];                                   // uniform addresses: scalar loads
+    const int ncol_all = A.rowptr[m0 + XBM < A.n ? m0 + XBM : A.n] - e_lo;
+    const bool cols_in_lds = ncol_all <= XCOLS;
     int cv[NCV];
-    auto request_rows = [&](int t) {                 // rowptr slice + feature rows of tile t
-        const int m0 = t * XBM;
-        if (threadIdx.x <= XBM) {
-            const int r = m0 + threadIdx.x;
-            rpv = A.rowptr[r < A.n ? r : A.n];
-        }
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            const int row = m0 + (p * 4 + wid) * RPW + sub;
-            xin[p] = (ok && row < A.n) ? X[(int64_t)row * ldx4 + l] : f4_zero();
-        }
-    };
-    auto request_cols = [&](int lo, int cnt) {       // column indices of a tile whose edge range is known
-#pragma unroll
-        for (int i = 0; i < NCV; ++i) {
-            const int idx = threadIdx.x + 256 * i;
-            cv[i] = (cnt <= XCOLS && idx < cnt) ? A.col[lo + idx] : 0;
-        }
-    };
-    request_rows(tile);
-    bf16x8 wres[RES ? RCH : 1][2][3][NTW];
-    if constexpr (RES) {
-#pragma unroll
-        for (int c = 0; c < RLATE; ++c)
-            if (c * KC < A.Kp) load_b_x6<N, NTW>(wres[c], W1, A.Kp, c * KC, lane_off);
-    } else {
-        load_b_x6<N, NTW>(wres[0], W1, A.Kp, 0, lane_off);
+    for (int i = 0; i < NCV; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        cv[i] = (cols_in_lds && idx < ncol_all) ? A.col[e_lo + idx] : 0;
     }
-    {
-        const int m0 = tile * XBM, m1 = m0 + XBM < A.n ? m0 + XBM : A.n;
-        e_lo = A.rowptr[m0];                          // uniform addresses: scalar loads
-        ncol_all = A.rowptr[m1] - e_lo;
-        request_cols(e_lo, ncol_all);
+    // park the tile's inputs in LDS
+    if (threadIdx.x <= XBM) rp[threadIdx.x] = rpv;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int m = (p * 4 + wid) * RPW + sub;
+        if (ok) *reinterpret_cast<float4 *>(Xs + m * A.K + 4 * l) = xin[p];
     }
+#pragma unroll
+    for (int i = 0; i < NCV; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        if (cols_in_lds && idx < ncol_all) cs[idx] = cv[i];
+    }
+    // zero the K padding columns of the three aggregated pieces
+    for (int idx = threadIdx.x; idx < 3 * XBM * (A.Kp - A.K); idx += 256) {
+        const int per = XBM * (A.Kp - A.K);
+        const int q = idx / per, rem = idx - q * per;
+        const int m = rem / (A.Kp - A.K), k = A.K + rem % (A.Kp - A.K);
+        *reinterpret_cast<__bf16 *>(Ap + q * XBM * sa + m * sa + k * 2) = (__bf16)0.f;
+    }
+    lds_barrier();
+    XSTAMP(1); XSTAMP(2);
 
-    for (;;) {
-        const int m0 = tile * XBM;
-        const bool cols_in_lds = ncol_all <= XCOLS;
-        // ---- (0) park the tile's inputs in LDS ------------------------------------------------------------
-        if (threadIdx.x <= XBM) rp[threadIdx.x] = rpv;
+    // ---- (1) gather from LDS, split, park the three pieces --------------------------------------------------
+    // Neighbours outside the tile (molecules straddle tile borders) come from global memory: the loads of
+    // two passes are requested together, after the LDS part, so the tile pays one L2 round trip per two
+    // passes instead of one per pass.
+    constexpr int FB = PASSES < 2 ? PASSES : 2;
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            const int m = (p * 4 + wid) * RPW + sub;
-            if (ok) *reinterpret_cast<float4 *>(Xs + m * A.K + 4 * l) = xin[p];
-        }
+    for (int pg = 0; pg < PASSES; pg += FB) {
+        float4 accv[FB];
+        int far[FB][4];
 #pragma unroll
-        for (int i = 0; i < NCV; ++i) {
-            const int idx = threadIdx.x + 256 * i;
-            if (cols_in_lds && idx < ncol_all) cs[idx] = cv[i];
-        }
-        // zero the K padding columns of the three aggregated pieces
-        for (int idx = threadIdx.x; idx < 3 * XBM * (A.Kp - A.K); idx += 256) {
-            const int per = XBM * (A.Kp - A.K);
-            const int q = idx / per, rem = idx - q * per;
-            const int m = rem / (A.Kp - A.K), k = A.K + rem % (A.Kp - A.K);
-            *reinterpret_cast<__bf16 *>(Ap + q * XBM * sa + m * sa + k * 2) = (__bf16)0.f;
-        }
-        lds_barrier();
-        XSTAMP(1);
-
-        // ---- prefetch: rowptr slice, feature rows and edge range of the next tile --------------------------
-        const int tnext = tile + (int)gridDim.x;
-        const bool has_next = RES && tnext < ntiles;
-        int e_lo_n = 0, ncol_n = 0;
-        if (has_next) {
-            request_rows(tnext);
-            const int q0 = tnext * XBM, q1 = q0 + XBM < A.n ? q0 + XBM : A.n;
-            e_lo_n = A.rowptr[q0];
-            ncol_n = A.rowptr[q1] - e_lo_n;
-        }
-        XSTAMP(2);
-
-        // ---- (1) gather from LDS, split, park the three pieces ------------------------------------------
-        // Neighbours outside the tile (molecules straddle tile borders) come from global memory: the
-        // loads of two passes are requested together, after the LDS part, so the tile pays one L2
-        // round trip per two passes instead of one per pass.
-        constexpr int FB = PASSES < 2 ? PASSES : 2;
+        for (int pp = 0; pp < FB; ++pp) {
+            const int m = ((pg + pp) * 4 + wid) * RPW + sub;
+            const int row = m0 + m;
+            const int e0 = rp[m], cnt = rp[m + 1] - e0;
+            const int lo4 = ok ? 4 * l : 0;
+            accv[pp] = *reinterpret_cast<const float4 *>(Xs + m * A.K + lo4);
+            accv[pp].x *= A.self_coef; accv[pp].y *= A.self_coef;
+            accv[pp].z *= A.self_coef; accv[pp].w *= A.self_coef;
 #pragma unroll
-        for (int pg = 0; pg < PASSES; pg += FB) {
-            float4 accv[FB];
-            int far[FB][4];
+            for (int q = 0; q < 4; ++q) {
+                int ci = e0 + q - e_lo;
+                ci = (q < cnt && ci < XCOLS) ? ci : 0;
+                const int c = cs[ci];
+                const int j = (q < cnt && cols_in_lds) ? c : row;
+                const int jl = j - m0;
+                const bool in_tile = jl >= 0 && jl < XBM;
+                far[pp][q] = (in_tile || !ok) ? -1 : j;
+                const bool use = in_tile && j != row;
+                const float4 u = *reinterpret_cast<const float4 *>(Xs + (use ? jl : m) * A.K + lo4);
+                f4_fma(accv[pp], use ? 1.f : 0.f, u);
+            }
+        }
+        float4 fu[FB][4];
 #pragma unroll
-            for (int pp = 0; pp < FB; ++pp) {
-                const int m = ((pg + pp) * 4 + wid) * RPW + sub;
-                const int row = m0 + m;
+        for (int pp = 0; pp < FB; ++pp)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                fu[pp][q] = f4_zero();
+                if (far[pp][q] >= 0) fu[pp][q] = X[(int64_t)far[pp][q] * ldx4 + l];
+            }
+#pragma unroll
+        for (int pp = 0; pp < FB; ++pp) {
+            const int m = ((pg + pp) * 4 + wid) * RPW + sub;
+            const int row = m0 + m;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f4_add(accv[pp], fu[pp][q]);
+            if (ok) {
                 const int e0 = rp[m], cnt = rp[m + 1] - e0;
-                const int lo4 = ok ? 4 * l : 0;
-                accv[pp] = *reinterpret_cast<const float4 *>(Xs + m * A.K + lo4);
-                accv[pp].x *= A.self_coef; accv[pp].y *= A.self_coef;
-                accv[pp].z *= A.self_coef; accv[pp].w *= A.self_coef;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int ci = e0 + q - e_lo;
-                    ci = (q < cnt && ci < XCOLS) ? ci : 0;
-                    const int c = cs[ci];
-                    const int j = (q < cnt && cols_in_lds) ? c : row;
-                    const int jl = j - m0;
-                    const bool in_tile = jl >= 0 && jl < XBM;
-                    far[pp][q] = (in_tile || !ok) ? -1 : j;
-                    const bool use = in_tile && j != row;
-                    const float4 u = *reinterpret_cast<const float4 *>(Xs + (use ? jl : m) * A.K + lo4);
-                    f4_fma(accv[pp], use ? 1.f : 0.f, u);
+                const int first = cols_in_lds ? 4 : 0;
+                for (int e = e0 + first; e < e0 + cnt; ++e) {
+                    const int jj = A.col[e];
+                    if (jj != row) f4_add(accv[pp], X[(int64_t)jj * ldx4 + l]);
                 }
-            }
-            float4 fu[FB][4];
-#pragma unroll
-            for (int pp = 0; pp < FB; ++pp)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    fu[pp][q] = f4_zero();
-                    if (far[pp][q] >= 0) fu[pp][q] = X[(int64_t)far[pp][q] * ldx4 + l];
-                }
-            if constexpr (RES) {
-                if (pg + FB >= PASSES) {
-#pragma unroll
-                    for (int c = RLATE; c < RCH; ++c)
-                        if (c * KC < A.Kp) load_b_x6<N, NTW>(wres[c], W1, A.Kp, c * KC, lane_off);
-                }
-            }
-#pragma unroll
-            for (int pp = 0; pp < FB; ++pp) {
-                const int m = ((pg + pp) * 4 + wid) * RPW + sub;
-                const int row = m0 + m;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) f4_add(accv[pp], fu[pp][q]);
-                if (ok) {
-                    const int e0 = rp[m], cnt = rp[m + 1] - e0;
-                    const int first = cols_in_lds ? 4 : 0;
-                    for (int e = e0 + first; e < e0 + cnt; ++e) {
-                        const int jj = A.col[e];
-                        if (jj != row) f4_add(accv[pp], X[(int64_t)jj * ldx4 + l]);
-                    }
-                    const Split3 s0 = split3(accv[pp].x), s1 = split3(accv[pp].y), s2 = split3(accv[pp].z),
-                                 s3 = split3(accv[pp].w);
-                    bf16x4 h = {s0.hi, s1.hi, s2.hi, s3.hi}, md = {s0.mid, s1.mid, s2.mid, s3.mid},
-                           lo = {s0.lo, s1.lo, s2.lo, s3.lo};
-                    char *dst = Ap + m * sa + 8 * l;
-                    *reinterpret_cast<bf16x4 *>(dst) = h;
-                    *reinterpret_cast<bf16x4 *>(dst + XBM * sa) = md;
-                    *reinterpret_cast<bf16x4 *>(dst + 2 * XBM * sa) = lo;
-                }
-            }
-        }
-        lds_barrier();
-        XSTAMP(3);
-
-        // ---- (2) hidden = act(agg @ W1 + b1), split, park -------------------------------------------------
-        f32x16 acc0[MT][NTW], acc1[MT][NTW];
-        auto zero = [&]() {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { acc0[mt][nt][r] = 0.f; acc1[mt][nt][r] = 0.f; }
-        };
-        zero();
-        if constexpr (RES) {
-            gemm_x6_resident<N, NTW, MT, XBM>(acc0, acc1, Ap, sa, A.Kp, wres, true, W2, N, RCH, lane_off, fi, fh);
-            if (has_next) request_cols(e_lo_n, ncol_n);
-        } else {
-            gemm_x6<N, NTW, MT, XBM>(acc0, acc1, Ap, sa, W1, A.Kp, lane_off, fi, fh, wres[0]);
-            load_b_x6<N, NTW>(wres[0], W2, N, 0, lane_off);
-        }
-        XSTAMP(4);
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = n_base + nt * 32 + 8 * g + 4 * fh;         // four consecutive output columns
-                const float4 b = A.b1 ? *reinterpret_cast<const float4 *>(A.b1 + c) : f4_zero();
-                const float4 sl = (ACT == BLGNN_ACT_PRELU && A.epi.act_param)
-                                      ? *reinterpret_cast<const float4 *>(A.epi.act_param + c) : f4_zero();
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int m = mt * 32 + fi;
-                    const Split3 s0 = split3(act_t<ACT>(acc0[mt][nt][4 * g + 0] + acc1[mt][nt][4 * g + 0] + b.x, sl.x));
-                    const Split3 s1 = split3(act_t<ACT>(acc0[mt][nt][4 * g + 1] + acc1[mt][nt][4 * g + 1] + b.y, sl.y));
-                    const Split3 s2 = split3(act_t<ACT>(acc0[mt][nt][4 * g + 2] + acc1[mt][nt][4 * g + 2] + b.z, sl.z));
-                    const Split3 s3 = split3(act_t<ACT>(acc0[mt][nt][4 * g + 3] + acc1[mt][nt][4 * g + 3] + b.w, sl.w));
-                    bf16x4 h = {s0.hi, s1.hi, s2.hi, s3.hi}, md = {s0.mid, s1.mid, s2.mid, s3.mid},
-                           lo = {s0.lo, s1.lo, s2.lo, s3.lo};
-                    char *dst = Hp + m * SH + c * 2;
-                    *reinterpret_cast<bf16x4 *>(dst) = h;
-                    *reinterpret_cast<bf16x4 *>(dst + XBM * SH) = md;
-                    *reinterpret_cast<bf16x4 *>(dst + 2 * XBM * SH) = lo;
-                }
-            }
-        lds_barrier();
-        XSTAMP(5);
-
-        // ---- (3) y = affine(act(hidden @ W2 + b2)) -> LDS staging -> row stores -----------------------------
-        zero();
-        if constexpr (RES)
-            gemm_x6_resident<N, NTW, MT, XBM>(acc0, acc1, Hp, SH, N, wres, has_next, W1, A.Kp, RLATE, lane_off,
-                                              fi, fh);
-        else
-            gemm_x6<N, NTW, MT, XBM>(acc0, acc1, Hp, SH, W2, N, lane_off, fi, fh, wres[0]);
-        XSTAMP(6);
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = n_base + nt * 32 + 8 * g + 4 * fh;
-                const float4 b = A.b2 ? *reinterpret_cast<const float4 *>(A.b2 + c) : f4_zero();
-                const float4 sl = (ACT == BLGNN_ACT_PRELU && A.epi.act_param)
-                                      ? *reinterpret_cast<const float4 *>(A.epi.act_param + c) : f4_zero();
-                float4 sc = {1.f, 1.f, 1.f, 1.f}, sh = f4_zero();
-                if (A.epi.bn_scale) sc = *reinterpret_cast<const float4 *>(A.epi.bn_scale + c);
-                if (A.epi.bn_scale && A.epi.bn_shift) sh = *reinterpret_cast<const float4 *>(A.epi.bn_shift + c);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int m = mt * 32 + fi;
-                    float4 v;
-                    v.x = act_t<ACT>(acc0[mt][nt][4 * g + 0] + acc1[mt][nt][4 * g + 0] + b.x, sl.x);
-                    v.y = act_t<ACT>(acc0[mt][nt][4 * g + 1] + acc1[mt][nt][4 * g + 1] + b.y, sl.y);
-                    v.z = act_t<ACT>(acc0[mt][nt][4 * g + 2] + acc1[mt][nt][4 * g + 2] + b.z, sl.z);
-                    v.w = act_t<ACT>(acc0[mt][nt][4 * g + 3] + acc1[mt][nt][4 * g + 3] + b.w, sl.w);
-                    if (A.epi.bn_scale) {
-                        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-                        v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-                    }
-                    *reinterpret_cast<float4 *>(Ys + m * LDO + c) = v;
-                }
-            }
-        lds_barrier();
-        XSTAMP(7);
-        for (int idx = threadIdx.x; idx < XBM * N4; idx += 256) {
-            const int m = idx / N4, c4 = idx % N4;
-            const int row = m0 + m;
-            if (row >= A.n) continue;
-            const float4 v = *reinterpret_cast<const float4 *>(Ys + m * LDO + 4 * c4);
-            float *dst = A.y + (int64_t)row * A.ldy + 4 * c4;
-            if (vec_out) *reinterpret_cast<float4 *>(dst) = v;
-            else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
-        }
-        XSTAMP(8);
-        if (!has_next) break;
-        // the next tile's inputs overwrite rp / cs / region 1, none of which the stores above read;
-        // region 0 is written again only after the next barrier
-        tile = tnext; e_lo = e_lo_n; ncol_all = ncol_n;
-    }
-}
-
-// ---- role-split persistent kernel (N = 128, K <= 128) ---------------------------------------------
-// One workgroup of eight waves per CU loops over 32-row tiles.  Waves 0-3 are the matrix waves:
-// weights live in their registers (the registers GEMM1 frees are refilled with W2, those GEMM2 frees
-// with W1 for the next tile) and they only run GEMM + epilogue.  Waves 4-7 are the feeder waves: they
-// own every global access of the activations -- request the next tiles' rows / indices, park them in
-// LDS, gather + split into the operand pieces, and write finished output tiles back -- so the HBM / L2
-// round trips of tile t+1 run under the MFMAs of tile t.  Two workgroup barriers per tile:
-//   first half   matrix: GEMM1(pieces t) -> hidden pieces     feeder: store out(t-1), park inputs(t+1)
-//   second half  matrix: GEMM2(hidden t) -> out tile t        feeder: gather(t+1) -> pieces, request(t+2)
-// Every LDS buffer is written in one half and read in the other, so none needs double buffering.
-template <int LG, int ACT>
-__global__ void __launch_bounds__(512, 1) k_gin_layer_x6ws(const GinX6Args A) {
-    constexpr int N = 128, NTW = 1, MT = 1, XBM = 32;
-    constexpr int RPW = WAVE / LG;
-    constexpr int PASSES = XBM / (4 * RPW);
-    constexpr int LDO = N + 4;
-    constexpr int SH = N * 2 + 16;
-    constexpr int NCV = XCOLS / 256;
-    constexpr int N4 = N / 4;
-    extern __shared__ float4 lds4[];
-    char *lds = reinterpret_cast<char *>(lds4);
-    const int sa = A.Kp * 2 + 16;
-    char *Ap = lds;                                              // [3][XBM][sa]   pieces of the aggregate
-    char *Hp = Ap + 3 * XBM * sa;                                // [3][XBM][SH]   pieces of the hidden tile
-    float *Ys = reinterpret_cast<float *>(Hp + 3 * XBM * SH);    // [XBM][LDO]     fp32 output tile
-    float *Xs = Ys + XBM * LDO;                                  // [XBM][K]       fp32 input rows
-    float *par = Xs + XBM * A.K;                                 // [5][N]         b1, b2, slope, scale, shift
-    int *rp = reinterpret_cast<int *>(par + 5 * N);              // [XBM + 4]
-    int *cs = rp + XBM + 4;                                      // [XCOLS]
-    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
-    const bool matrix = __builtin_amdgcn_readfirstlane(wid) < 4;   // wave-uniform by construction
-    const int ft = threadIdx.x - 256;                            // feeder thread id (valid when !matrix)
-    const int fw = wid - 4;
-    const int fi = lane & 31, fh = lane >> 5;
-    const int sub = lane / LG, l = lane % LG;
-    const int n_base = (wid & 3) * 32;
-    const wrsrc_t W1 = weight_rsrc(A.w1p, A.Kp, N), W2 = weight_rsrc(A.w2p, N, N);
-    const unsigned lane_off = weight_lane_off<N>(n_base, fi, fh);
-    const int k4n = A.K >> 2;
-    const bool ok = l < k4n;
-    const float4 *__restrict__ X = reinterpret_cast<const float4 *>(A.x);
-    const int64_t ldx4 = A.ldx >> 2;
-    const int ntiles = (A.n + XBM - 1) / XBM;
-    const int cnt = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup
-    const bool vec_out = (A.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(A.y) & 15u) == 0);
-    auto tile_of = [&](int i) { return (int)blockIdx.x + i * (int)gridDim.x; };
-
-    // feeder state: the rows / indices of the tile that is parked next
-    int rpv = 0, e_lo = 0, ncol_all = 0;       // parked tile (valid between park and gather)
-    int e_lo_q = 0, ncol_q = 0;                // tile whose rows / indices are in flight
-    float4 xin[PASSES];
-    int cv[NCV];
-    // Edge range of a tile = (rowptr[first row], rowptr[last row + 1]).  Loaded with a VECTOR load
-    // (lane 0 / lane 1 of every feeder wave) and broadcast by readlane when consumed: a scalar load
-    // would share lgkmcnt with the LDS traffic, and because scalar loads return out of order every
-    // LDS wait issued while one is in flight becomes a wait for that L2 round trip.
-    int rng = 0;
-    auto request_range = [&](int t) {
-        const int m0 = t * XBM, m1 = m0 + XBM < A.n ? m0 + XBM : A.n;
-        if (lane < 2) rng = A.rowptr[lane == 0 ? m0 : m1];
-    };
-    auto request_rows = [&](int t, int lo, int hi) {             // rows, rowptr slice, indices of tile t
-        const int m0 = t * XBM;
-        e_lo_q = lo; ncol_q = hi - lo;
-        if (ft <= XBM) {
-            const int r = m0 + ft;
-            rpv = A.rowptr[r < A.n ? r : A.n];
-        }
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            const int row = m0 + (p * 4 + fw) * RPW + sub;
-            xin[p] = (ok && row < A.n) ? X[(int64_t)row * ldx4 + l] : f4_zero();
-        }
-#pragma unroll
-        for (int i = 0; i < NCV; ++i) {
-            const int idx = ft + 256 * i;
-            cv[i] = (ncol_q <= XCOLS && idx < ncol_q) ? A.col[e_lo_q + idx] : 0;
-        }
-    };
-    auto park = [&]() {                                          // registers -> LDS (rows, rowptr slice, indices)
-        e_lo = e_lo_q; ncol_all = ncol_q;
-        if (ft <= XBM) rp[ft] = rpv;
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            const int m = (p * 4 + fw) * RPW + sub;
-            if (ok) *reinterpret_cast<float4 *>(Xs + m * A.K + 4 * l) = xin[p];
-        }
-#pragma unroll
-        for (int i = 0; i < NCV; ++i) {
-            const int idx = ft + 256 * i;
-            if (ncol_all <= XCOLS && idx < ncol_all) cs[idx] = cv[i];
-        }
-    };
-    auto gather = [&](int t) {                                   // LDS rows (+ far rows) -> split -> pieces
-        const int m0 = t * XBM;
-        const bool cols_in_lds = ncol_all <= XCOLS;
-        constexpr int FB = PASSES;                               // all out-of-tile loads of the tile in one batch
-        GSTAMP(0);
-#pragma unroll
-        for (int pg = 0; pg < PASSES; pg += FB) {
-            float4 accv[FB];
-            int far[FB][4];
-#pragma unroll
-            for (int pp = 0; pp < FB; ++pp) {
-                const int m = ((pg + pp) * 4 + fw) * RPW + sub;
-                const int row = m0 + m;
-                const int e0 = rp[m], ne = rp[m + 1] - e0;
-                const int lo4 = ok ? 4 * l : 0;
-                accv[pp] = *reinterpret_cast<const float4 *>(Xs + m * A.K + lo4);
-                accv[pp].x *= A.self_coef; accv[pp].y *= A.self_coef;
-                accv[pp].z *= A.self_coef; accv[pp].w *= A.self_coef;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int ci = e0 + q - e_lo;
-                    ci = (q < ne && ci < XCOLS) ? ci : 0;
-                    const int c = cs[ci];
-                    const int j = (q < ne && cols_in_lds) ? c : row;
-                    const int jl = j - m0;
-                    const bool in_tile = jl >= 0 && jl < XBM;
-                    far[pp][q] = (in_tile || !ok) ? -1 : j;
-                    const bool use = in_tile && j != row;
-                    const float4 u = *reinterpret_cast<const float4 *>(Xs + (use ? jl : m) * A.K + lo4);
-                    f4_fma(accv[pp], use ? 1.f : 0.f, u);
-                }
-            }
-            GSTAMP(1);
-            float4 fu[FB][4];
-#pragma unroll
-            for (int pp = 0; pp < FB; ++pp)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    fu[pp][q] = f4_zero();
-                    if (far[pp][q] >= 0) fu[pp][q] = X[(int64_t)far[pp][q] * ldx4 + l];
-                }
-            GSTAMP(2);
-#pragma unroll
-            for (int pp = 0; pp < FB; ++pp) {
-                const int m = ((pg + pp) * 4 + fw) * RPW + sub;
-                const int row = m0 + m;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) f4_add(accv[pp], fu[pp][q]);
-                if (pp == FB - 1) GSTAMP(3);
-                if (ok) {
-                    const int e0 = rp[m], ne = rp[m + 1] - e0;
-                    const int first = cols_in_lds ? 4 : 0;
-                    for (int e = e0 + first; e < e0 + ne; ++e) {
-                        const int jj = A.col[e];
-                        if (jj != row) f4_add(accv[pp], X[(int64_t)jj * ldx4 + l]);
-                    }
-                    const Split3 s0 = split3(accv[pp].x), s1 = split3(accv[pp].y), s2 = split3(accv[pp].z),
-                                 s3 = split3(accv[pp].w);
-                    bf16x4 h = {s0.hi, s1.hi, s2.hi, s3.hi}, md = {s0.mid, s1.mid, s2.mid, s3.mid},
-                           lo = {s0.lo, s1.lo, s2.lo, s3.lo};
-                    char *dst = Ap + m * sa + 8 * l;
-                    *reinterpret_cast<bf16x4 *>(dst) = h;
-                    *reinterpret_cast<bf16x4 *>(dst + XBM * sa) = md;
-                    *reinterpret_cast<bf16x4 *>(dst + 2 * XBM * sa) = lo;
-                }
-            }
-            GSTAMP(4);
-        }
-    };
-    auto store_tile = [&](int t) {                               // LDS output tile -> global rows
-        const int m0 = t * XBM;
-        for (int idx = ft; idx < XBM * N4; idx += 256) {
-            const int m = idx / N4, c4 = idx % N4;
-            const int row = m0 + m;
-            if (row >= A.n) continue;
-            const float4 v = *reinterpret_cast<const float4 *>(Ys + m * LDO + 4 * c4);
-            float *dst = A.y + (int64_t)row * A.ldy + 4 * c4;
-            if (vec_out) *reinterpret_cast<float4 *>(dst) = v;
-            else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
-        }
-    };
-
-    // The two roles run separate loops (same trip count, two barriers per trip) so that each gets its
-    // own register allocation: the weight registers are not live in the feeder's code and the
-    // feeder's load buffers are not live in the matrix code.
-    if (matrix) {
-        bf16x8 wres[RCH][2][3][NTW], wres2[RCH][2][3][NTW];     // both weight matrices stay in registers
-#pragma unroll
-        for (int c = 0; c < RCH; ++c) {
-            if (c * KC < A.Kp) load_b_x6<N, NTW>(wres[c], W1, A.Kp, c * KC, lane_off);
-            load_b_x6<N, NTW>(wres2[c], W2, N, c * KC, lane_off);
-        }
-        lds_barrier();                                           // trip -1: the feeder parks / gathers tile 0
-        lds_barrier();
-        for (int i = 0; i < cnt; ++i) {
-            f32x16 acc0[MT][NTW], acc1[MT][NTW];
-            WSTAMP(0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[0][0][r] = 0.f; acc1[0][0][r] = 0.f; }
-            gemm_x6_resident<N, NTW, MT, XBM>(acc0, acc1, Ap, sa, A.Kp, wres, false, W2, N, RCH, lane_off, fi, fh);
-            WSTAMP(1);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = n_base + 8 * g + 4 * fh;                   // four consecutive output columns
-                const float4 b = *reinterpret_cast<const float4 *>(par + c);
-                const float4 sl = *reinterpret_cast<const float4 *>(par + 2 * N + c);
-                const Split3 s0 = split3(act_t<ACT>(acc0[0][0][4 * g + 0] + acc1[0][0][4 * g + 0] + b.x, sl.x));
-                const Split3 s1 = split3(act_t<ACT>(acc0[0][0][4 * g + 1] + acc1[0][0][4 * g + 1] + b.y, sl.y));
-                const Split3 s2 = split3(act_t<ACT>(acc0[0][0][4 * g + 2] + acc1[0][0][4 * g + 2] + b.z, sl.z));
-                const Split3 s3 = split3(act_t<ACT>(acc0[0][0][4 * g + 3] + acc1[0][0][4 * g + 3] + b.w, sl.w));
+                const Split3 s0 = split3(accv[pp].x), s1 = split3(accv[pp].y), s2 = split3(accv[pp].z),
+                             s3 = split3(accv[pp].w);
                 bf16x4 h = {s0.hi, s1.hi, s2.hi, s3.hi}, md = {s0.mid, s1.mid, s2.mid, s3.mid},
                        lo = {s0.lo, s1.lo, s2.lo, s3.lo};
-                char *dst = Hp + fi * SH + c * 2;
+                char *dst = Ap + m * sa + 8 * l;
+                *reinterpret_cast<bf16x4 *>(dst) = h;
+                *reinterpret_cast<bf16x4 *>(dst + XBM * sa) = md;
+                *reinterpret_cast<bf16x4 *>(dst + 2 * XBM * sa) = lo;
+            }
+        }
+    }
+    lds_barrier();
+    XSTAMP(3);
+
+    // ---- (2) hidden = act(agg @ W1 + b1), split, park -----------------------------------------------------
+    f32x16 acc0[MT][NTW], acc1[MT][NTW];
+    auto zero = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[mt][nt][r] = 0.f; acc1[mt][nt][r] = 0.f; }
+    };
+    zero();
+    gemm_x6<N, NTW, MT, XBM>(acc0, acc1, Ap, sa, W1, A.Kp, lane_off, fi, fh, wfrag);
+    load_b_x6<N, NTW>(wfrag, W2, N, 0, lane_off);
+    XSTAMP(4);
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = n_base + nt * 32 + 8 * g + 4 * fh;             // four consecutive output columns
+            const float4 b = A.b1 ? *reinterpret_cast<const float4 *>(A.b1 + c) : f4_zero();
+            const float4 sl = (ACT == BLGNN_ACT_PRELU && A.epi.act_param)
+                                  ? *reinterpret_cast<const float4 *>(A.epi.act_param + c) : f4_zero();
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = mt * 32 + fi;
+                const Split3 s0 = split3(act_t<ACT>(acc0[mt][nt][4 * g + 0] + acc1[mt][nt][4 * g + 0] + b.x, sl.x));
+                const Split3 s1 = split3(act_t<ACT>(acc0[mt][nt][4 * g + 1] + acc1[mt][nt][4 * g + 1] + b.y, sl.y));
+                const Split3 s2 = split3(act_t<ACT>(acc0[mt][nt][4 * g + 2] + acc1[mt][nt][4 * g + 2] + b.z, sl.z));
+                const Split3 s3 = split3(act_t<ACT>(acc0[mt][nt][4 * g + 3] + acc1[mt][nt][4 * g + 3] + b.w, sl.w));
+                bf16x4 h = {s0.hi, s1.hi, s2.hi, s3.hi}, md = {s0.mid, s1.mid, s2.mid, s3.mid},
+                       lo = {s0.lo, s1.lo, s2.lo, s3.lo};
+                char *dst = Hp + m * SH + c * 2;
                 *reinterpret_cast<bf16x4 *>(dst) = h;
                 *reinterpret_cast<bf16x4 *>(dst + XBM * SH) = md;
                 *reinterpret_cast<bf16x4 *>(dst + 2 * XBM * SH) = lo;
             }
-            WSTAMP(2);
-            lds_barrier();
-            WSTAMP(3);
+        }
+    lds_barrier();
+    XSTAMP(5);
+
+    // ---- (3) y = affine(act(hidden @ W2 + b2)) -> LDS staging -> row stores ---------------------------------
+    zero();
+    gemm_x6<N, NTW, MT, XBM>(acc0, acc1, Hp, SH, W2, N, lane_off, fi, fh, wfrag);
+    XSTAMP(6);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[0][0][r] = 0.f; acc1[0][0][r] = 0.f; }
-            gemm_x6_resident<N, NTW, MT, XBM>(acc0, acc1, Hp, SH, N, wres2, false, W1, A.Kp, RCH, lane_off, fi, fh);
-            WSTAMP(4);
+    for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = n_base + 8 * g + 4 * fh;
-                const float4 b = *reinterpret_cast<const float4 *>(par + N + c);
-                const float4 sl = *reinterpret_cast<const float4 *>(par + 2 * N + c);
-                const float4 sc = *reinterpret_cast<const float4 *>(par + 3 * N + c);
-                const float4 sh = *reinterpret_cast<const float4 *>(par + 4 * N + c);
+        for (int g = 0; g < 4; ++g) {
+            const int c = n_base + nt * 32 + 8 * g + 4 * fh;
+            const float4 b = A.b2 ? *reinterpret_cast<const float4 *>(A.b2 + c) : f4_zero();
+            const float4 sl = (ACT == BLGNN_ACT_PRELU && A.epi.act_param)
+                                  ? *reinterpret_cast<const float4 *>(A.epi.act_param + c) : f4_zero();
+            float4 sc = {1.f, 1.f, 1.f, 1.f}, sh = f4_zero();
+            if (A.epi.bn_scale) sc = *reinterpret_cast<const float4 *>(A.epi.bn_scale + c);
+            if (A.epi.bn_scale && A.epi.bn_shift) sh = *reinterpret_cast<const float4 *>(A.epi.bn_shift + c);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = mt * 32 + fi;
                 float4 v;
-                v.x = act_t<ACT>(acc0[0][0][4 * g + 0] + acc1[0][0][4 * g + 0] + b.x, sl.x);
-                v.y = act_t<ACT>(acc0[0][0][4 * g + 1] + acc1[0][0][4 * g + 1] + b.y, sl.y);
-                v.z = act_t<ACT>(acc0[0][0][4 * g + 2] + acc1[0][0][4 * g + 2] + b.z, sl.z);
-                v.w = act_t<ACT>(acc0[0][0][4 * g + 3] + acc1[0][0][4 * g + 3] + b.w, sl.w);
+                v.x = act_t<ACT>(acc0[mt][nt][4 * g + 0] + acc1[mt][nt][4 * g + 0] + b.x, sl.x);
+                v.y = act_t<ACT>(acc0[mt][nt][4 * g + 1] + acc1[mt][nt][4 * g + 1] + b.y, sl.y);
+                v.z = act_t<ACT>(acc0[mt][nt][4 * g + 2] + acc1[mt][nt][4 * g + 2] + b.z, sl.z);
+                v.w = act_t<ACT>(acc0[mt][nt][4 * g + 3] + acc1[mt][nt][4 * g + 3] + b.w, sl.w);
                 if (A.epi.bn_scale) {
                     v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
                     v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
                 }
-                *reinterpret_cast<float4 *>(Ys + fi * LDO + c) = v;
+                *reinterpret_cast<float4 *>(Ys + m * LDO + c) = v;
             }
-            WSTAMP(5);
-            lds_barrier();
-            WSTAMP(6);
         }
-    } else {
-        request_range(tile_of(0));
-        request_rows(tile_of(0), __builtin_amdgcn_readlane(rng, 0), __builtin_amdgcn_readlane(rng, 1));
-        if (cnt > 1) request_range(tile_of(1));
-        if (ft < N) {                                            // epilogue parameters, defaults when absent
-            par[ft] = A.b1 ? A.b1[ft] : 0.f;
-            par[N + ft] = A.b2 ? A.b2[ft] : 0.f;
-            par[2 * N + ft] = (ACT == BLGNN_ACT_PRELU && A.epi.act_param) ? A.epi.act_param[ft] : 0.f;
-            par[3 * N + ft] = A.epi.bn_scale ? A.epi.bn_scale[ft] : 1.f;
-            par[4 * N + ft] = (A.epi.bn_scale && A.epi.bn_shift) ? A.epi.bn_shift[ft] : 0.f;
-        }
-        for (int idx = ft; idx < 3 * XBM * (A.Kp - A.K); idx += 256) {    // K padding of the pieces: zero, once
-            const int per = XBM * (A.Kp - A.K);
-            const int q = idx / per, rem = idx - q * per;
-            const int m = rem / (A.Kp - A.K), k = A.K + rem % (A.Kp - A.K);
-            *reinterpret_cast<__bf16 *>(Ap + q * XBM * sa + m * sa + k * 2) = (__bf16)0.f;
-        }
-        for (int i = -1; i < cnt; ++i) {
-            WSTAMP(0);
-            if (i >= 1) store_tile(tile_of(i - 1));
-            WSTAMP(1);
-            if (i + 1 < cnt) park();
-            WSTAMP(2);
-            lds_barrier();
-            WSTAMP(3);
-            if (i + 1 < cnt) {
-                // range of tile i+2, requested one tile ago
-                const int lo2 = __builtin_amdgcn_readlane(rng, 0), hi2 = __builtin_amdgcn_readlane(rng, 1);
-                if (i + 3 < cnt) request_range(tile_of(i + 3));
-                gather(tile_of(i + 1));
-                WSTAMP(4);
-                if (i + 2 < cnt) request_rows(tile_of(i + 2), lo2, hi2);
-            }
-            WSTAMP(5);
-            lds_barrier();
-            WSTAMP(6);
-        }
-        if (cnt > 0) store_tile(tile_of(cnt - 1));
+    lds_barrier();
+    XSTAMP(7);
+    for (int idx = threadIdx.x; idx < XBM * N4; idx += 256) {
+        const int m = idx / N4, c4 = idx % N4;
+        const int row = m0 + m;
+        if (row >= A.n) continue;
+        const float4 v = *reinterpret_cast<const float4 *>(Ys + m * LDO + 4 * c4);
+        float *dst = A.y + (int64_t)row * A.ldy + 4 * c4;
+        if (vec_out) *reinterpret_cast<float4 *>(dst) = v;
+        else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
     }
-}
-
-static size_t x6ws_lds_bytes(int K, int Kp) {
-    return (size_t)3 * 32 * (Kp * 2 + 16) + (size_t)3 * 32 * (128 * 2 + 16) + (size_t)32 * 132 * 4 +
-           (size_t)32 * K * 4 + 5 * 128 * 4 + sizeof(int) * (32 + 4 + XCOLS);
-}
-
-static int cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            n = v;
-        else
-            n = 256;
-    }
-    return n;
+    XSTAMP(8);
 }
 
 static size_t x6_lds_bytes(int K, int Kp, int N, int XBM) {
@@ -793,51 +406,19 @@ static size_t x6_lds_bytes(int K, int Kp, int N, int XBM) {
     return r0 + r1 + sizeof(int) * (XBM + 4 + XCOLS);
 }
 
-template <int N, int LG, int ACT, int XBM, bool RES>
-static int launch_x6_res(const GinX6Args &A, hipStream_t s) {
+template <int N, int LG, int ACT, int XBM>
+static int launch_x6(const GinX6Args &A, hipStream_t s) {
     static size_t declared = 0;
     const size_t bytes = x6_lds_bytes(A.K, A.Kp, N, XBM);
     if (bytes > declared && bytes > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gin_layer_x6<N, LG, ACT, XBM, RES>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gin_layer_x6<N, LG, ACT, XBM>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
             return fail(BLGNN_ERR_LAUNCH, "gin_layer_x6: cannot raise the dynamic LDS limit to %zu bytes", bytes);
         declared = bytes;
     }
-    int blocks = (A.n + XBM - 1) / XBM;
-    if (RES) {                                   // persistent: two workgroups per CU
-        const int slots = 2 * cu_count();
-        if (blocks > slots) blocks = slots;
-    }
-    hipLaunchKernelGGL((k_gin_layer_x6<N, LG, ACT, XBM, RES>), dim3(blocks), dim3(256), bytes, s, A);
+    const int blocks = (A.n + XBM - 1) / XBM;
+    hipLaunchKernelGGL((k_gin_layer_x6<N, LG, ACT, XBM>), dim3(blocks), dim3(256), bytes, s, A);
     return launch_status("gin_layer_x6");
-}
-
-template <int LG, int ACT>
-static int launch_x6ws(const GinX6Args &A, hipStream_t s) {
-    static size_t declared = 0;
-    const size_t bytes = x6ws_lds_bytes(A.K, A.Kp);
-    if (bytes > declared) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gin_layer_x6ws<LG, ACT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
-            return fail(BLGNN_ERR_LAUNCH, "gin_layer_x6: cannot raise the dynamic LDS limit to %zu bytes", bytes);
-        declared = bytes;
-    }
-    int blocks = (A.n + 31) / 32;
-    if (blocks > cu_count()) blocks = cu_count();
-    hipLaunchKernelGGL((k_gin_layer_x6ws<LG, ACT>), dim3(blocks), dim3(512), bytes, s, A);
-    return launch_status("gin_layer_x6");
-}
-
-template <int N, int LG, int ACT, int XBM>
-static int launch_x6(const GinX6Args &A, hipStream_t s) {
-    static const int mode = getenv("BLGNN_X6_MODE") ? atoi(getenv("BLGNN_X6_MODE")) : 2;
-    if constexpr (N == 128 && LG <= 32 && XBM == 32) {
-        if (mode == 2) return launch_x6ws<LG, ACT>(A, s);
-    }
-    // weights resident in registers when both matrices fit four 32-deep chunks per wave
-    const bool res = mode == 1;
-    if (res && N == 128 && LG <= 32) return launch_x6_res<N, LG, ACT, XBM, (N == 128 && LG <= 32)>(A, s);
-    return launch_x6_res<N, LG, ACT, XBM, false>(A, s);
 }
 
 template <int N, int LG, int XBM>
