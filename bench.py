@@ -321,10 +321,18 @@ def micro_roofline(device):
                            "frac": b / t / 1e9 / PEAK_HBM_GBPS, "alg_bytes": b, "us": t * 1e6}
     w = torch.randn(d, d, device=device) / 16
     h = torch.empty_like(x)
-    t = timeit(lambda: ops.linear(x, w, out=h), reps=10)
+    t = timeit(lambda: ops.linear(x, w, out=h, transform="f32"), reps=10)
     f = 2.0 * n * d * d
     res["linear_d256"] = {"bound": "mfma", "achieved": f / t / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
                           "unit": "TFLOP/s", "frac": f / t / 1e12 / PEAK_F32_MFMA_TFLOPS, "us": t * 1e6}
+    # same GEMM as six bf16 MFMA products per fp32 product: executed rate against the bf16 peak, and
+    # the launch against HBM (X read once, Y written once)
+    t = timeit(lambda: ops.linear(x, w, out=h, transform="bf16x6"), reps=10)
+    by = 8.0 * n * d
+    res["linear_d256_bf16x6"] = {"bound": "mfma", "achieved": 6.0 * f / t / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": 6.0 * f / t / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                                 "algorithmic_f32_tflops": f / t / 1e12, "alg_hbm_GBps": by / t / 1e9,
+                                 "alg_hbm_frac": by / t / 1e9 / PEAK_HBM_GBPS, "us": t * 1e6}
     return res
 
 

@@ -5,15 +5,18 @@ arithmetic step is a libblgnn kernel.  All functions require CUDA(HIP) fp32
 tensors and raise on anything else -- there is deliberately no CPU path.
 """
 
+import weakref
+
 import torch
 
 from . import _lib
 from ._lib import call, ACT_IDS, GAT_GROUP, REDUCE_MEAN, REDUCE_SUM
+from .config import FLAGS
 
 __all__ = [
     "CSR", "csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear",
     "gat_conv", "gcn_conv", "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum",
-    "row_degree", "link_pred_head", "pack_weight_x6", "gin_layer_x6", "gin_layer_x6_supported", "gin_stack", "molecule_tiles", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
+    "row_degree", "link_pred_head", "pack_weight_x6", "linear_x6_supported", "gin_layer_x6", "gin_layer_x6_supported", "gin_stack", "molecule_tiles", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
     "require_device",
 ]
 
@@ -222,9 +225,38 @@ def gin_stack(csr, x0, tile_row, tile_mol, seg, layers, pooled, pool_cols, kind=
     return pooled
 
 
+# Packed (bf16x6) images of weight matrices, keyed by the weight tensor OBJECT (weak reference, so an
+# entry can never be matched by a different tensor that happens to reuse the address) and refreshed
+# when the tensor is written in place (_version) or moved.
+_PACKED = {}
+LINEAR_X6_MIN_TILES = 256      # 128x128 output tiles; below one per CU the f32 kernels' smaller tiles win
+
+
+def _packed_weight(w_kn):
+    key = id(w_kn)
+    hit = _PACKED.get(key)
+    stamp = (w_kn.data_ptr(), w_kn._version, tuple(w_kn.shape), w_kn.stride(0))
+    if hit is not None and hit[0]() is w_kn and hit[1] == stamp:
+        return hit[2]
+    if len(_PACKED) > 512:
+        for k in [k for k, v in _PACKED.items() if v[0]() is None]:
+            del _PACKED[k]
+    packed = pack_weight_x6(w_kn)
+    _PACKED[key] = (weakref.ref(w_kn), stamp, packed)
+    return packed
+
+
+def linear_x6_supported(x, w_kn):
+    tiles = ((x.shape[0] + 127) // 128) * ((w_kn.shape[1] + 127) // 128)
+    return (x.shape[1] % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+            and tiles >= LINEAR_X6_MIN_TILES)
+
+
 def linear(x, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn_shift=None,
-           rowvec=None, rowvec_w=None, out=None):
-    """epi(x @ w_kn + bias [+ rowvec (x) rowvec_w]); w_kn is [K, N] row-major."""
+           rowvec=None, rowvec_w=None, out=None, transform=None):
+    """epi(x @ w_kn + bias [+ rowvec (x) rowvec_w]); w_kn is [K, N] row-major.
+    ``transform``: "bf16x6" (bf16 matrix cores, fp32-equivalent, large M only), "f32" (exact-f32
+    MFMA) or None = FLAGS.feature_transform."""
     xp, ldx = _mat(x, "x")
     wp, ldw = _mat(w_kn, "w")
     M, K = x.shape
@@ -233,6 +265,13 @@ def linear(x, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn
     N = w_kn.shape[1]
     y = _out(out, M, N, x)
     yp, ldy = _mat(y, "out")
+    if transform is None:
+        transform = getattr(FLAGS, "feature_transform", "bf16x6")
+    if transform == "bf16x6" and K > 0 and N > 0 and linear_x6_supported(x, w_kn):
+        call("blgnn_linear_x6", xp, ldx, _packed_weight(w_kn).data_ptr(), yp, ldy, M, N, K, _vec(bias, "bias"),
+             _vec(rowvec, "rowvec"), _vec(rowvec_w, "rowvec_w"), _act(act), _vec(act_param, "act_param"),
+             _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), _stream())
+        return y
     call("blgnn_linear", xp, ldx, wp, ldw, yp, ldy, M, N, K, _vec(bias, "bias"),
          _vec(rowvec, "rowvec"), _vec(rowvec_w, "rowvec_w"), _act(act), _vec(act_param, "act_param"),
          _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), _stream())

@@ -14,12 +14,10 @@
 // pre-split and packed [piece][K/8][N][8] (blgnn_pack_weight_x6) so a B fragment is one 16-byte
 // load per lane.
 #include "gin_common.hpp"
+#include "x6_common.hpp"
 #include <stdlib.h>
 
 namespace blgnn {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #ifdef X6_STAMP
 __device__ unsigned long long g_x6_stamps[16];
@@ -29,21 +27,6 @@ __device__ unsigned long long g_x6_stamps[16];
 #endif
 
 constexpr int XCOLS = 256;       // column indices of a tile kept in LDS (32 rows x mean degree 2.1 = 68)
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits for
-// every global load / store in flight -- exactly the prefetches and write-backs these kernels keep
-// running across phase boundaries.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-struct Split3 { __bf16 hi, mid, lo; };
-__device__ __forceinline__ Split3 split3(float x) {
-    Split3 s;
-    s.hi = (__bf16)x;
-    const float r1 = x - (float)s.hi;
-    s.mid = (__bf16)r1;
-    s.lo = (__bf16)(r1 - (float)s.mid);
-    return s;
-}
 
 // ---- weight packing: W[K,N] fp32 -> [3][Kp/8][N][8] bf16 -----------------------------------------
 __global__ void k_pack_x6(const float *__restrict__ w, int64_t ldw, int K, int N, int Kp,

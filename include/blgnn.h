@@ -234,6 +234,16 @@ int blgnn_linear(const float *x, int64_t ldx, const float *w, int64_t ldw,
                  int32_t act, const float *act_param, const float *bn_scale,
                  const float *bn_shift, void *stream);
 
+/* blgnn_linear with the product on the bf16 matrix cores at fp32 accuracy (bf16x6: operands split
+ * in three bf16 pieces, six MFMAs per product, see blgnn_gin_layer_x6).  Same call sites as
+ * blgnn_linear; w_packed = blgnn_pack_weight_x6(W[K,N]).  Needs K % 4 == 0, ldx % 4 == 0 and
+ * 16-byte aligned x / w_packed, otherwise BLGNN_ERR_UNSUPPORTED (use blgnn_linear). */
+int blgnn_linear_x6(const float *x, int64_t ldx, const void *w_packed, float *y,
+                    int64_t ldy, int32_t M, int32_t N, int32_t K, const float *bias,
+                    const float *rowvec, const float *rowvec_w, int32_t act,
+                    const float *act_param, const float *bn_scale,
+                    const float *bn_shift, void *stream);
+
 /* ---- GMN cross-graph attention ------------------------------------------ */
 
 /* model/layers_gmn.py:55-84.  Graphs (2k, 2k+1) of seg[] form pair k.

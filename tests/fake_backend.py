@@ -65,7 +65,7 @@ def spmm_sum(csr, x, self_coef=0.0, skip_self=False, w=None, out=None):
 
 
 def linear(x, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn_shift=None,
-           rowvec=None, rowvec_w=None, out=None):
+           rowvec=None, rowvec_w=None, out=None, transform=None):
     if act not in real_ops.ACT_IDS:
         raise ValueError("Unknown activation function {}".format(act))
     v = x @ w_kn

@@ -134,6 +134,43 @@ def test_linear_epilogue(device, act):
     assert max_err(got, ref) < TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(32768, 128, 128), (33001, 64, 52), (32800, 100, 36), (11000, 300, 260),
+                                   (32769, 1, 8), (16500, 256, 1024)])
+def test_linear_bf16x6_shapes(device, M, N, K):
+    """bf16x6 split GEMM (large-M path of ops.linear) == fp64 oracle at the fp32 bar"""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(K, N, generator=g) / max(K, 1) ** 0.5
+    b = torch.randn(N, generator=g)
+    ref = x.double() @ w.double() + b.double()
+    xd, wd = x.to(device), w.to(device)
+    assert ops.linear_x6_supported(xd, wd)
+    got = ops.linear(xd, wd, b.to(device), transform="bf16x6")
+    assert max_err(got, ref) < TOL
+    exact = ops.linear(xd, wd, b.to(device), transform="f32")
+    assert max_err(exact, ref) < TOL
+    # the packed image follows in-place weight updates
+    wd.mul_(2.0)
+    assert max_err(ops.linear(xd, wd, b.to(device), transform="bf16x6"), 2.0 * (x.double() @ w.double()) + b.double()) < TOL
+
+
+@pytest.mark.parametrize("act", ["identity", "relu", "prelu", "sigmoid", "tanh"])
+def test_linear_bf16x6_epilogue(device, act):
+    M, N, K = 33321, 96, 72
+    g = torch.Generator().manual_seed(77)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g) / 8, torch.randn(N, generator=g)
+    slope, scale, shift = torch.rand(N, generator=g), torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    rv, rw = torch.rand(M, generator=g) * 3, torch.randn(N, generator=g)
+    ref = x.double() @ w.double() + b.double() + rv.double().view(-1, 1) * rw.double().view(1, -1)
+    ref = oracle.apply_act(ref, act, slope.double()) * scale.double() + shift.double()
+    dv = lambda t: t.to(device)
+    wide = torch.zeros(M, N + 8, device=device)
+    got = ops.linear(dv(x), dv(w), dv(b), act=act, act_param=dv(slope), bn_scale=dv(scale),
+                     bn_shift=dv(shift), rowvec=dv(rv), rowvec_w=dv(rw), out=wide[:, 4:4 + N], transform="bf16x6")
+    assert max_err(got, ref) < TOL
+    assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + N:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("K,N,act", [(52, 64, "relu"), (52, 128, "relu"), (40, 256, "relu"), (64, 64, "identity"),
                                      (128, 128, "relu"), (128, 128, "identity"), (256, 256, "relu"),
                                      (256, 128, "prelu"), (64, 256, "tanh")])
