@@ -125,29 +125,36 @@ __device__ __forceinline__ void mfma_chunk_x6(f32x16 (&acc0)[MT][NTW], f32x16 (&
 }
 
 // Streaming variant (wide layers): weight chunks double-buffered in registers, one chunk ahead.
-template <int N, int NTW, int MT, int XBM>
+// Weight chunks stream through a ring of RING register buffers, RING-1 chunks ahead of the MFMAs
+// (an L2 round trip is ~1.5 k cycles under load, one chunk of MFMAs ~0.4 k).  On entry the caller has
+// requested chunks 0 .. RING-2 into w[0] .. w[RING-2] (x6_prefetch).
+template <int N, int NTW, int RING>
+__device__ __forceinline__ void x6_prefetch(bf16x8 (&w)[RING][2][3][NTW], wrsrc_t Wp, int Kp, unsigned lane_off) {
+#pragma unroll
+    for (int u = 0; u < RING - 1; ++u)
+        if (u * KC < Kp) load_b_x6<N, NTW>(w[u], Wp, Kp, u * KC, lane_off);
+}
+
+template <int N, int NTW, int MT, int XBM, int RING>
 __device__ __forceinline__ void gemm_x6(f32x16 (&acc0)[MT][NTW], f32x16 (&acc1)[MT][NTW], const char *Ap, int sa,
                                         wrsrc_t Wp, int Kp, unsigned lane_off, int fi, int fh,
-                                        bf16x8 (&bcur)[2][3][NTW]) {
-    bf16x8 bnxt[2][3][NTW];
+                                        bf16x8 (&w)[RING][2][3][NTW]) {
     const char *arow = Ap + fi * sa + fh * 16;                   // lane (row fi, k half fh)
-    for (int kc = 0; kc < Kp; kc += KC) {
-        const bool more = kc + KC < Kp;
-        if (more) load_b_x6<N, NTW>(bnxt, Wp, Kp, kc + KC, lane_off);
-        mfma_chunk_x6<NTW, MT, XBM>(acc0, acc1, arow, sa, kc, bcur);
-        if (more) {
+    for (int kc = 0; kc < Kp; kc += RING * KC) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-#pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) bcur[s][q][nt] = bnxt[s][q][nt];
+        for (int u = 0; u < RING; ++u) {
+            const int k = kc + u * KC;
+            if (k < Kp) {
+                if (k + (RING - 1) * KC < Kp)
+                    load_b_x6<N, NTW>(w[(u + RING - 1) % RING], Wp, Kp, k + (RING - 1) * KC, lane_off);
+                mfma_chunk_x6<NTW, MT, XBM>(acc0, acc1, arow, sa, k, w[u]);
+            }
         }
     }
 }
 
 template <int N, int LG, int ACT, int XBM>
-__global__ void __launch_bounds__(256, XBM == 32 ? 3 : 1) k_gin_layer_x6(const GinX6Args A) {
+__global__ void __launch_bounds__(256, (XBM == 32 && N == 128) ? 3 : 1) k_gin_layer_x6(const GinX6Args A) {
     constexpr int NTW = N / 128;                    // 4 waves side by side over N
     constexpr int MT = XBM / 32;
     constexpr int RPW = WAVE / LG;
@@ -156,6 +163,7 @@ __global__ void __launch_bounds__(256, XBM == 32 ? 3 : 1) k_gin_layer_x6(const G
     constexpr int SH = N * 2 + 16;                  // hidden piece row stride (bytes)
     constexpr int NCV = XCOLS / 256;
     constexpr int N4 = N / 4;
+    constexpr int RING = NTW == 1 ? 3 : 2;          // weight chunk buffers (24 NTW VGPRs each)
     extern __shared__ float4 lds4[];
     char *lds = reinterpret_cast<char *>(lds4);
     const int sa = A.Kp * 2 + 16;                   // aggregated piece row stride (bytes)
@@ -197,8 +205,8 @@ __global__ void __launch_bounds__(256, XBM == 32 ? 3 : 1) k_gin_layer_x6(const G
         const int row = m0 + (p * 4 + wid) * RPW + sub;
         xin[p] = (ok && row < A.n) ? X[(int64_t)row * ldx4 + l] : f4_zero();
     }
-    bf16x8 wfrag[2][3][NTW];
-    load_b_x6<N, NTW>(wfrag, W1, A.Kp, 0, lane_off);
+    bf16x8 wfrag[RING][2][3][NTW];
+    x6_prefetch<N, NTW, RING>(wfrag, W1, A.Kp, lane_off);
     const int e_lo = A.rowptr[m0];                                   // uniform addresses: scalar loads
     const int ncol_all = A.rowptr[m0 + XBM < A.n ? m0 + XBM : A.n] - e_lo;
     const bool cols_in_lds = ncol_all <= XCOLS;
@@ -233,7 +241,7 @@ __global__ void __launch_bounds__(256, XBM == 32 ? 3 : 1) k_gin_layer_x6(const G
     // ---- (1) gather from LDS, split, park the three pieces --------------------------------------------------
     // Neighbours outside the tile (molecules straddle tile borders) come from global memory: the loads of
     // two passes are requested together, after the LDS part, so the tile pays one L2 round trip per two
-    // passes instead of one per pass.
+    // passes instead of one per pass (four at once would need 64 more VGPRs: spills at 3 workgroups/CU).
     constexpr int FB = PASSES < 2 ? PASSES : 2;
 #pragma unroll
     for (int pg = 0; pg < PASSES; pg += FB) {
@@ -308,17 +316,27 @@ __global__ void __launch_bounds__(256, XBM == 32 ? 3 : 1) k_gin_layer_x6(const G
                 for (int r = 0; r < 16; ++r) { acc0[mt][nt][r] = 0.f; acc1[mt][nt][r] = 0.f; }
     };
     zero();
-    gemm_x6<N, NTW, MT, XBM>(acc0, acc1, Ap, sa, W1, A.Kp, lane_off, fi, fh, wfrag);
-    load_b_x6<N, NTW>(wfrag, W2, N, 0, lane_off);
+    // epilogue parameters are requested BEFORE the GEMM they follow, so their L2 round trip runs under
+    // the MFMAs (a lane owns the four consecutive columns c .. c+3 of each of its 4 NTW groups)
+    float4 pb[NTW][4], psl[NTW][4];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = n_base + nt * 32 + 8 * g + 4 * fh;
+            pb[nt][g] = A.b1 ? *reinterpret_cast<const float4 *>(A.b1 + c) : f4_zero();
+            psl[nt][g] = (ACT == BLGNN_ACT_PRELU && A.epi.act_param)
+                             ? *reinterpret_cast<const float4 *>(A.epi.act_param + c) : f4_zero();
+        }
+    gemm_x6<N, NTW, MT, XBM, RING>(acc0, acc1, Ap, sa, W1, A.Kp, lane_off, fi, fh, wfrag);
+    x6_prefetch<N, NTW, RING>(wfrag, W2, N, lane_off);
     XSTAMP(4);
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int c = n_base + nt * 32 + 8 * g + 4 * fh;             // four consecutive output columns
-            const float4 b = A.b1 ? *reinterpret_cast<const float4 *>(A.b1 + c) : f4_zero();
-            const float4 sl = (ACT == BLGNN_ACT_PRELU && A.epi.act_param)
-                                  ? *reinterpret_cast<const float4 *>(A.epi.act_param + c) : f4_zero();
+            const float4 b = pb[nt][g], sl = psl[nt][g];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int m = mt * 32 + fi;
@@ -339,19 +357,26 @@ __global__ void __launch_bounds__(256, XBM == 32 ? 3 : 1) k_gin_layer_x6(const G
 
     // ---- (3) y = affine(act(hidden @ W2 + b2)) -> LDS staging -> row stores ---------------------------------
     zero();
-    gemm_x6<N, NTW, MT, XBM>(acc0, acc1, Hp, SH, W2, N, lane_off, fi, fh, wfrag);
+    float4 psc[NTW][4], psh[NTW][4];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = n_base + nt * 32 + 8 * g + 4 * fh;
+            pb[nt][g] = A.b2 ? *reinterpret_cast<const float4 *>(A.b2 + c) : f4_zero();
+            psc[nt][g] = float4{1.f, 1.f, 1.f, 1.f};
+            psh[nt][g] = f4_zero();
+            if (A.epi.bn_scale) psc[nt][g] = *reinterpret_cast<const float4 *>(A.epi.bn_scale + c);
+            if (A.epi.bn_scale && A.epi.bn_shift) psh[nt][g] = *reinterpret_cast<const float4 *>(A.epi.bn_shift + c);
+        }
+    gemm_x6<N, NTW, MT, XBM, RING>(acc0, acc1, Hp, SH, W2, N, lane_off, fi, fh, wfrag);
     XSTAMP(6);
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int c = n_base + nt * 32 + 8 * g + 4 * fh;
-            const float4 b = A.b2 ? *reinterpret_cast<const float4 *>(A.b2 + c) : f4_zero();
-            const float4 sl = (ACT == BLGNN_ACT_PRELU && A.epi.act_param)
-                                  ? *reinterpret_cast<const float4 *>(A.epi.act_param + c) : f4_zero();
-            float4 sc = {1.f, 1.f, 1.f, 1.f}, sh = f4_zero();
-            if (A.epi.bn_scale) sc = *reinterpret_cast<const float4 *>(A.epi.bn_scale + c);
-            if (A.epi.bn_scale && A.epi.bn_shift) sh = *reinterpret_cast<const float4 *>(A.epi.bn_shift + c);
+            const float4 b = pb[nt][g], sl = psl[nt][g], sc = psc[nt][g], sh = psh[nt][g];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int m = mt * 32 + fi;
