@@ -16,16 +16,21 @@ namespace blgnn {
 template <int CH>
 __global__ void __launch_bounds__(512)
 k_gmn_match(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__restrict__ x,
-            int64_t ldx, float *__restrict__ u, int64_t ldu, int32_t d, int32_t lds_floats) {
+            int64_t ldx, float *__restrict__ u, int64_t ldu, int32_t d, int32_t lds_floats, int32_t skip_small,
+            int32_t parts) {
     extern __shared__ float4 smem4[];
     float *smem = reinterpret_cast<float *>(smem4);
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
     const int d4 = d >> 2;
     const int lds_ld = d + 4;
 
-    for (int pair = blockIdx.x; pair < num_pairs; pair += gridDim.x) {
+    // `parts` workgroups share one pair (interleaved query rows): when the matrix-core kernel has taken
+    // the small pairs, the few big ones left would otherwise each serialise on a single workgroup
+    for (int item = blockIdx.x; item < num_pairs * parts; item += gridDim.x) {
+        const int pair = item / parts, part = item - pair * parts;
         const int s0 = seg[2 * pair], s1 = seg[2 * pair + 1], s2 = seg[2 * pair + 2];
         const int n1 = s1 - s0, n2 = s2 - s1, nt = n1 + n2;
+        if (n1 <= skip_small && n2 <= skip_small) continue;   // the matrix-core kernel owns this pair
         const bool staged = (int64_t)nt * lds_ld <= (int64_t)lds_floats;
         __syncthreads();                                   // previous pair done with LDS
         if (staged) {
@@ -37,7 +42,8 @@ k_gmn_match(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__r
         }
         __syncthreads();
 
-        for (int t = wid; t < nt; t += (int)(blockDim.x / WAVE)) {
+        const int nwaves = (int)(blockDim.x / WAVE);
+        for (int t = wid + nwaves * part; t < nt; t += nwaves * parts) {
             const bool first = t < n1;
             const int arow_g = s0 + t;                     // global row of the query node
             const int b0 = first ? n1 : 0;                 // partner rows (local index)
@@ -127,6 +133,209 @@ k_gmn_match(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__r
     }
 }
 
+
+// ---- matrix-core variant for pairs with both graphs <= 64 nodes (95 % of DrugBank / DrugCombo pairs) --------
+// The work of a pair is three small GEMMs -- S = G1 G2^T over the D features, U1 = A G2, U2 = A'^T-free
+// form A' G1 -- so it runs on v_mfma_f32_32x32x2_f32 (exact f32; 6 n1 n2 D flop is nothing for the matrix
+// cores, the scalar kernel above spends 25x the roofline time on it).  One 256-thread workgroup per pair,
+// features streamed in 64-column chunks (next chunk prefetched into registers under the MFMAs):
+//   pass 1  S_raw += G1c G2c^T, the four waves split the chunk's k range; row norms on the side;
+//           partials summed in a fixed order, scaled to cosines;
+//   softmax over rows (A, n1 x n2) and over columns (A', stored n2 x n1), padded entries zero;
+//   pass 2  per chunk: waves 0-1  U1c = G1c - A G2c,  waves 2-3  U2c = G2c - A' G1c, written straight out.
+typedef float f32x16m __attribute__((ext_vector_type(16)));
+constexpr int MM = 64;              // max nodes per graph
+constexpr int MCH = 64;             // feature chunk
+constexpr int MLD = 65;             // LDS row stride (floats)
+constexpr int MREG = MM * MLD;      // floats per LDS region
+
+__global__ void __launch_bounds__(256, 2)
+k_gmn_match_mfma(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__restrict__ x, int64_t ldx,
+                 float *__restrict__ u, int64_t ldu, int32_t d) {
+    extern __shared__ float4 smem4[];
+    float *R0 = reinterpret_cast<float *>(smem4);       // pass 1: G1 chunk | partial 2 ; later A' (n2 x n1)
+    float *R1 = R0 + MREG;                              // pass 1: G2 chunk | partial 3 ; pass 2: G2 chunk
+    float *R2 = R1 + MREG;                              // partial 0 -> S ; pass 2: G1 chunk
+    float *R3 = R2 + MREG;                              // partial 1 ; later A (n1 x n2)
+    float *inv = R3 + MREG;                             // [2 * MM] 1 / max(|row|, eps)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fi = lane & 31, fh = lane >> 5;
+    const int lrow = tid >> 4, lc4 = tid & 15;          // chunk loads: 16 threads x 16 B per row, 16 rows per pass
+    const int nch = d / MCH;
+    // Buffer addressing: one per-thread VGPR offset + a wave-uniform SGPR offset per access, so the
+    // 8 chunk loads and 32 result stores of a thread cost no address registers (with flat 64-bit
+    // addresses hipcc keeps one address pair per access live across the chunk loop and spills).
+    // Rows past the end of x read as zero (bounds-checked descriptor).
+    const int total_rows = seg[2 * num_pairs];
+    typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t RX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x), 0, (int)(((int64_t)(total_rows - 1) * ldx + d) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t RU = __builtin_amdgcn_make_buffer_rsrc(
+        u, 0, (int)(((int64_t)(total_rows - 1) * ldu + d) * 4), 0x00020000);
+    const unsigned xvoff = (unsigned)(lrow * ldx + 4 * lc4) * 4u;
+    const unsigned uvoff = (unsigned)(4 * fh * ldu + fi) * 4u;
+
+    for (int pair = blockIdx.x; pair < num_pairs; pair += gridDim.x) {
+        const int s0 = seg[2 * pair], s1 = seg[2 * pair + 1], s2 = seg[2 * pair + 2];
+        const int n1 = s1 - s0, n2 = s2 - s1;
+        if (n1 > MM || n2 > MM || (n1 == 0 && n2 == 0)) continue;          // big pairs: scalar kernel
+        const int TM = (n1 + 31) >> 5, TN = (n2 + 31) >> 5;
+        // rows of the two 64-row slabs this thread loads: slab row = lrow + 16 p, p < 4 (G1) and p < 4 (G2)
+        float4 pre[8];
+        auto fetch = [&](int c) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int r = lrow + 16 * (p & 3);
+                const bool first = p < 4;
+                const bool live = first ? r < n1 : r < n2;
+                const unsigned soff = (unsigned)(((first ? s0 : s1) + 16 * (p & 3)) * ldx + c * MCH) * 4u;
+                const u32x4m v = __builtin_amdgcn_raw_buffer_load_b128(RX, xvoff, soff, 0);
+                const float4 f = __builtin_bit_cast(float4, v);
+                pre[p] = live ? f : f4_zero();
+            }
+        };
+        auto park = [&](float *G1c, float *G2c) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                float *dst = (p < 4 ? G1c : G2c) + (lrow + 16 * (p & 3)) * MLD + 4 * lc4;
+                dst[0] = pre[p].x; dst[1] = pre[p].y; dst[2] = pre[p].z; dst[3] = pre[p].w;
+            }
+        };
+
+        // ---- pass 1: raw similarities + squared norms -----------------------------------------------------
+        f32x16m acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        float nsq[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) nsq[p] = 0.f;
+        fetch(0);
+        for (int c = 0; c < nch; ++c) {
+            __syncthreads();                                   // previous chunk / previous pair done with R0, R1
+            park(R0, R1);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                nsq[p] = fmaf(pre[p].x, pre[p].x, nsq[p]); nsq[p] = fmaf(pre[p].y, pre[p].y, nsq[p]);
+                nsq[p] = fmaf(pre[p].z, pre[p].z, nsq[p]); nsq[p] = fmaf(pre[p].w, pre[p].w, nsq[p]);
+            }
+            if (c + 1 < nch) fetch(c + 1);
+            __syncthreads();
+            const int kb = wid * (MCH / 4);                    // this wave's 16 k of the chunk
+            if (TM == 1 && TN == 1) {                          // wave-uniform: one 32 x 32 tile
+#pragma unroll
+                for (int ks = 0; ks < MCH / 4; ks += 2)
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(R0[fi * MLD + kb + ks + fh],
+                                                                     R1[fi * MLD + kb + ks + fh], acc[0][0], 0, 0, 0);
+            } else {                                           // all four tiles (padding rows are zero)
+#pragma unroll
+                for (int ks = 0; ks < MCH / 4; ks += 2) {
+                    float a[2], b[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) a[i] = R0[(32 * i + fi) * MLD + kb + ks + fh];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) b[j] = R1[(32 * j + fi) * MLD + kb + ks + fh];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                       // all waves done reading the last chunk
+        // partial S of wave w -> region (w == 0 ? R2 : w == 1 ? R3 : w == 2 ? R0 : R1); norms -> inv
+        {
+            float *dstp = wid == 0 ? R2 : (wid == 1 ? R3 : (wid == 2 ? R0 : R1));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                        dstp[row * MLD + 32 * j + fi] = acc[i][j][r];
+                    }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                float v = nsq[p];
+                v += __shfl_xor(v, 1, WAVE); v += __shfl_xor(v, 2, WAVE);
+                v += __shfl_xor(v, 4, WAVE); v += __shfl_xor(v, 8, WAVE);
+                if (lc4 == 0) inv[(p < 4 ? 0 : MM) + lrow + 16 * (p & 3)] = 1.f / fmaxf(sqrtf(v), 1e-12f);
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < MM * MM; idx += 256) {       // cosine similarity, fixed summation order
+            const int i = idx >> 6, j = idx & 63;
+            const int o = i * MLD + j;
+            R2[o] = (((R2[o] + R3[o]) + R0[o]) + R1[o]) * inv[i] * inv[MM + j];
+        }
+        __syncthreads();
+        // ---- softmax over rows (A -> R3) and over columns (A' -> R0, stored [j][i]) -----------------------------
+        if (tid < MM) {
+            const int i = tid;
+            float m = -INFINITY, l = 0.f;
+            if (i < n1) {
+                for (int j = 0; j < n2; ++j) m = fmaxf(m, R2[i * MLD + j]);
+                for (int j = 0; j < n2; ++j) l += expf(R2[i * MLD + j] - m);
+            }
+            const float il = (i < n1 && n2 > 0) ? 1.f / l : 0.f;
+            for (int j = 0; j < MM; ++j)
+                R3[i * MLD + j] = (i < n1 && j < n2) ? expf(R2[i * MLD + j] - m) * il : 0.f;
+        } else if (tid < 2 * MM) {
+            const int j = tid - MM;
+            float m = -INFINITY, l = 0.f;
+            if (j < n2) {
+                for (int i = 0; i < n1; ++i) m = fmaxf(m, R2[i * MLD + j]);
+                for (int i = 0; i < n1; ++i) l += expf(R2[i * MLD + j] - m);
+            }
+            const float il = (j < n2 && n1 > 0) ? 1.f / l : 0.f;
+            for (int i = 0; i < MM; ++i)
+                R0[j * MLD + i] = (j < n2 && i < n1) ? expf(R2[i * MLD + j] - m) * il : 0.f;
+        }
+        // ---- pass 2: U1 = G1 - A G2 (waves 0, 1), U2 = G2 - A' G1 (waves 2, 3), 32 columns per wave ---------------
+        fetch(0);
+        const bool second = wid >= 2;
+        const int ct = wid & 1;
+        const float *Am = second ? R0 : R3;                    // [rows of the output graph][partner rows]
+        const int TR = second ? TN : TM, TK = second ? TM : TN;
+        const int nrows = second ? n2 : n1;
+        const int64_t gbase = second ? s1 : s0;
+        for (int c = 0; c < nch; ++c) {
+            __syncthreads();                                   // softmax written / previous chunk consumed
+            park(R2, R1);                                      // G1 chunk -> R2, G2 chunk -> R1
+            if (c + 1 < nch) fetch(c + 1);
+            __syncthreads();
+            const float *Bm = second ? R2 : R1;                // partner graph's chunk
+            const float *Gm = second ? R1 : R2;                // own chunk
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (i >= TR) continue;
+                f32x16m o;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = 0.f;
+                for (int k = 0; k < 32 * TK; k += 2) {
+                    const float a = Am[(32 * i + fi) * MLD + k + fh];
+                    const float b = Bm[(k + fh) * MLD + 32 * ct + fi];
+                    o = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, o, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rc = 32 * i + (r & 3) + 8 * (r >> 2);      // + 4 fh = row inside the graph
+                    const unsigned soff = (unsigned)((gbase + rc) * ldu + c * MCH + 32 * ct) * 4u;
+                    if (rc + 4 * fh < nrows)
+                        __builtin_amdgcn_raw_buffer_store_b32(
+                            __builtin_bit_cast(unsigned int, Gm[(rc + 4 * fh) * MLD + 32 * ct + fi] - o[r]), RU, uvoff,
+                            soff, 0);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace blgnn
 
 using namespace blgnn;
@@ -146,14 +355,32 @@ extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const floa
     // a pair that does not fit reads its partner rows from L2 with one row per lane, which is
     // an order of magnitude slower), between 64 KiB (two 256-thread workgroups per CU) and
     // 150 KiB (one 512-thread workgroup per CU).
+    hipStream_t s = (hipStream_t)stream;
+    int skip_small = -1;
+    if (d % MCH == 0) {                                    // matrix-core kernel for pairs up to 64 x 64 nodes
+        static bool declared = false;
+        const int mbytes = (4 * MREG + 2 * MM) * (int)sizeof(float);
+        if (!declared) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gmn_match_mfma),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, mbytes) != hipSuccess)
+                return fail(BLGNN_ERR_LAUNCH, "gmn_match: cannot raise the dynamic LDS limit");
+            declared = true;
+        }
+        const int mblocks = num_pairs < 256 * 8 ? num_pairs : 256 * 8;
+        hipLaunchKernelGGL(k_gmn_match_mfma, dim3(mblocks), dim3(256), mbytes, s, seg, num_pairs, x, ldx, u, ldu, d);
+        const int rc = launch_status("gmn_match");
+        if (rc != BLGNN_OK) return rc;
+        skip_small = MM;
+    }
     size_t want = (size_t)128 * (d + 4) * sizeof(float);
     if (want < 64 * 1024) want = 64 * 1024;
     if (want > 150 * 1024) want = 150 * 1024;
     const int lds_bytes = (int)want;
     const int lds_floats = lds_bytes / 4;
     const int threads = lds_bytes > 80 * 1024 ? 512 : 256;
-    const int blocks = num_pairs < 256 * 8 ? num_pairs : 256 * 8;
-    hipStream_t s = (hipStream_t)stream;
+    const int parts = skip_small >= 0 ? 8 : 1;
+    const int64_t items = (int64_t)num_pairs * parts;
+    const int blocks = (int)(items < 256 * 8 ? items : 256 * 8);
     const int ch = (d / 4 + WAVE - 1) / WAVE;
 #define BLGNN_GMN_LAUNCH(CH_)                                                                       \
     do {                                                                                            \
@@ -165,7 +392,7 @@ extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const floa
             declared = lds_bytes;                                                                   \
         }                                                                                           \
         hipLaunchKernelGGL((k_gmn_match<CH_>), dim3(blocks), dim3(threads), lds_bytes, s, seg,      \
-                           num_pairs, x, ldx, u, ldu, d, lds_floats);                              \
+                           num_pairs, x, ldx, u, ldu, d, lds_floats, skip_small, parts);           \
     } while (0)
     if (ch <= 1) BLGNN_GMN_LAUNCH(1);
     else if (ch == 2) BLGNN_GMN_LAUNCH(2);

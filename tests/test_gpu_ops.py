@@ -370,7 +370,11 @@ def test_segment_reduce_multi_scale(device):
 
 
 @pytest.mark.parametrize("d,sizes", [(64, [5, 7, 1, 3, 24, 24]), (256, [40, 38, 2, 70, 64, 65]),
-                                     (512, [30, 31]), (256, [150, 170]), (128, [457, 12])])
+                                     (512, [30, 31]), (256, [150, 170]), (128, [457, 12]),
+                                     (256, [32, 32, 33, 31, 64, 64, 1, 64, 64, 1]),     # tile edges of the matrix-core kernel
+                                     (192, [28, 40, 0, 17, 9, 0]),                      # empty graphs on either side
+                                     (72, [20, 30, 44, 12]),                            # d % 64 != 0: scalar kernel
+                                     (128, [28] * 64)])
 def test_gmn_match(device, d, sizes):
     off = np.concatenate([[0], np.cumsum(sizes)])
     ind = [(int(off[i]), int(off[i + 1])) for i in range(len(sizes))]
