@@ -40,7 +40,7 @@ BATCH_PAIRS = 4096
 D = 128
 SEED = 20200614 + 2
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (same table)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA (same table)
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -56,8 +56,10 @@ def parse():
                     help="profiling aid: build rank 0's share of an N-GPU run on one GPU (no collective)")
     ap.add_argument("--fuse-lower", action="store_true",
                     help="run the lower level as ONE launch (blgnn_gin_stack) instead of one per GIN layer")
-    ap.add_argument("--exact-f32", action="store_true",
-                    help="run the fused GIN layer's transforms on the exact-f32 MFMA path instead of bf16x6")
+    ap.add_argument("--transform", choices=("f16x3", "bf16x6", "f32"), default="f16x3",
+                    help="how the fused GIN layer runs its dense transforms: fp16 two-piece split (default), "
+                         "bf16 three-piece split, or exact-f32 MFMA -- all fp32-equivalent")
+    ap.add_argument("--exact-f32", action="store_true", help="same as --transform f32")
     ap.add_argument("--no-overlap", action="store_true",
                     help="replay the lower and upper graphs of a step back to back on one stream")
     ap.add_argument("--no-graph", action="store_true",
@@ -91,7 +93,7 @@ class KernelTimer(object):
         return ms, self.work
 
 
-def build_workload(rank, world, device, transform="bf16x6"):
+def build_workload(rank, world, device, transform="f16x3"):
     import blgnn
     from blgnn.dist import ShardedLower
     n_drugs = DRUGS_PER_GPU * world
@@ -141,7 +143,7 @@ def main():
     from blgnn.batch import BatchData
     from blgnn.forward import all_molecule_pairs
 
-    transform = "f32" if args.exact_f32 else "bf16x6"
+    transform = "f32" if args.exact_f32 else args.transform
     if args.emulate_world > 1 and world == 1:
         ds, flags, data, model, sharded = build_workload(0, args.emulate_world, device, transform)
     else:
@@ -170,7 +172,7 @@ def main():
     # dominant kernel: the fused GIN layer (CSR gather -> LDS -> 2 matrix-core GEMMs -> epilogue),
     # bf16x6 variant by default (FLAGS.feature_transform), exact-f32 MFMA variant otherwise
     timer = KernelTimer()
-    real_gin, real_gin6 = ops.gin_layer, ops.gin_layer_x6
+    real_gin, real_gin6, real_gin3 = ops.gin_layer, ops.gin_layer_x6, ops.gin_layer_h3
     ops.gin_layer = timer.wrap(
         real_gin,
         lambda csr, x, w1, b1, w2, *a, **kw: (2.0 * x.shape[0] * (w1.shape[0] * w1.shape[1] + w2.shape[0] * w2.shape[1]),
@@ -181,7 +183,12 @@ def main():
         lambda csr, x, w1p, b1, w2p, b2, N, *a, **kw: (2.0 * x.shape[0] * (x.shape[1] * N + N * N),
                                                        4.0 * x.shape[0] * (x.shape[1] + N) + 4.0 * csr.nnz + 4.0 * (csr.n + 1)),
         lambda *a, **kw: True)
-    x6 = getattr(flags, "feature_transform", "bf16x6") == "bf16x6"
+    ops.gin_layer_h3 = timer.wrap(
+        real_gin3,
+        lambda csr, x, w1p, b1, w2p, b2, N, *a, **kw: (2.0 * x.shape[0] * (x.shape[1] * N + N * N),
+                                                       4.0 * x.shape[0] * (x.shape[1] + N) + 4.0 * csr.nnz + 4.0 * (csr.n + 1)),
+        lambda *a, **kw: True)
+    mode = getattr(flags, "feature_transform", "f16x3")
 
     # The forward is ~35 short launches: captured into HIP graphs and replayed, and consecutive
     # forwards are software-pipelined over two HIP streams (blgnn/engine.py): the molecular
@@ -232,7 +239,7 @@ def main():
     assert preds.shape == (BATCH_PAIRS, 1) and bool(torch.isfinite(preds).all())
 
     ms, work = timer.result()
-    ops.gin_layer, ops.gin_layer_x6 = real_gin, real_gin6
+    ops.gin_layer, ops.gin_layer_x6, ops.gin_layer_h3 = real_gin, real_gin6, real_gin3
     out = None
     if rank == 0:
         value = world * BATCH_PAIRS * args.steps / elapsed
@@ -240,19 +247,25 @@ def main():
         # (profiles/summarize_pmc.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction)
         traffic = None
         try:
-            name = "r01_gin_layer_x6_pmc_summary.json" if x6 else "r01_gin_layer_pmc_summary.json"
+            name = {"f16x3": "r01_gin_layer_h3_pmc_summary.json", "bf16x6": "r01_gin_layer_x6_pmc_summary.json",
+                    "f32": "r01_gin_layer_pmc_summary.json"}[mode]
             traffic = json.load(open(os.path.join(ROOT, "profiles", name)))["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         tflops = sum(w[0] for w in work) / (sum(ms) * 1e-3) / 1e12 if ms else 0.0
         alg_gbps = sum(w[1] for w in work) / (sum(ms) * 1e-3) / 1e9 if ms else 0.0
-        # bf16x6: every algorithmic fp32 product is six bf16 MFMA products -> the executed
-        # matrix-core rate is 6x the algorithmic one and is priced against the bf16 dense peak
-        mfma_mult, peak = (6.0, PEAK_BF16_MFMA_TFLOPS) if x6 else (1.0, PEAK_F32_MFMA_TFLOPS)
+        # split transforms: every algorithmic fp32 product is three fp16 (f16x3) or six bf16 (bf16x6) MFMA
+        # products -> the executed matrix-core rate is 3x / 6x the algorithmic one and is priced against the
+        # dense fp16 / bf16 peak (the same 2.5 PFLOP/s)
+        mfma_mult, peak = {"f16x3": (3.0, PEAK_BF16_MFMA_TFLOPS), "bf16x6": (6.0, PEAK_BF16_MFMA_TFLOPS),
+                           "f32": (1.0, PEAK_F32_MFMA_TFLOPS)}[mode]
+        kname = {"f16x3": "k_gin_layer_h3 (fused GIN layer: CSR gather in LDS + 2 GEMMs as 3 fp16 MFMA products per "
+                          "fp32 product + act/BN)",
+                 "bf16x6": "k_gin_layer_x6 (fused GIN layer: CSR gather in LDS + 2 GEMMs as 6 bf16 MFMA products per "
+                           "fp32 product + act/BN)",
+                 "f32": "k_gin_layer (fused GIN layer: CSR gather in LDS + 2 exact-f32 MFMA GEMMs + act/BN)"}[mode]
         roofline = {
-            "kernel": ("k_gin_layer_x6 (fused GIN layer: CSR gather in LDS + 2 GEMMs as 6 bf16 MFMA products "
-                       "per fp32 product + act/BN)") if x6 else
-                      "k_gin_layer (fused GIN layer: CSR gather in LDS + 2 exact-f32 MFMA GEMMs + act/BN)",
+            "kernel": kname,
             "bound": "mfma", "achieved": mfma_mult * tflops, "peak": peak, "unit": "TFLOP/s",
             "frac": mfma_mult * tflops / peak, "traffic": traffic,
             "algorithmic_f32_tflops": tflops, "frac_of_f32_mfma_peak": tflops / PEAK_F32_MFMA_TFLOPS,
@@ -263,7 +276,8 @@ def main():
             "metric": "DDI edge-pairs/sec (bi-level forward)",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (dense transforms as bf16x6 split MFMA, fp32-equivalent)" if x6 else "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"f16x3": "f32 (dense transforms as f16x3 split MFMA, fp32-equivalent)",
+                      "bf16x6": "f32 (dense transforms as bf16x6 split MFMA, fp32-equivalent)", "f32": "f32"}[mode],
             "data": "synthetic",
             "config": {"workload": "DrugBank-shape DDI, lower GIN x5 + upper GAT x3, d=128, "
                                    "batch=4096 edge pairs per GPU (BASELINE configs[1])",

@@ -35,6 +35,9 @@ SIGNATURES = {
     "blgnn_gin_layer": [_p, _p, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _p, _i32, _f32, _i32, _p, _p, _p,
                         _p, _i64, _p],
     "blgnn_pack_weight_x6": [_p, _i64, _i32, _i32, _p, _p],
+    "blgnn_pack_weight_h3": [_p, _i64, _i32, _i32, _p, _p],
+    "blgnn_gin_layer_h3": [_p, _p, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _p, _i32, _f32, _i32, _p, _p, _p,
+                           _p, _i64, _p],
     "blgnn_gin_layer_x6": [_p, _p, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _p, _i32, _f32, _i32, _p, _p, _p,
                            _p, _i64, _p],
     "blgnn_gin_stack": [_p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p,
@@ -57,7 +60,8 @@ SIGNATURES = {
     "blgnn_l2_normalize_rows": [_p, _i64, _p, _i64, _i32, _i32, _f32, _p],
     "blgnn_scatter_rows": [_p, _i64, _p, _p, _i64, _i32, _i32, _p],
 }
-LIBRARY_SYMBOLS = ["blgnn_version", "blgnn_last_error", "blgnn_device_count", "blgnn_packed_weight_x6_elems"]
+LIBRARY_SYMBOLS = ["blgnn_version", "blgnn_last_error", "blgnn_device_count", "blgnn_packed_weight_x6_elems",
+                   "blgnn_packed_weight_h3_elems"]
 
 _lib = None
 
@@ -86,6 +90,8 @@ def load():
     lib.blgnn_device_count.restype = ctypes.c_int
     lib.blgnn_packed_weight_x6_elems.argtypes = [_i32, _i32]
     lib.blgnn_packed_weight_x6_elems.restype = ctypes.c_int64
+    lib.blgnn_packed_weight_h3_elems.argtypes = [_i32, _i32]
+    lib.blgnn_packed_weight_h3_elems.restype = ctypes.c_int64
     _lib = lib
     return lib
 

@@ -64,7 +64,7 @@ def make_flags(model="higher_level_gnn", dataset="drugbank", lower_level_gnn_typ
                higher_level_gnn_type="gat", D_lower=64, D_higher=64,
                lower_level_num_layers=None, higher_level_num_layers=3, batch_size=None,
                device="cuda:0", node_aggr=None, bn=True, gnn_normalize=False,
-               gat_softmax_group="src", d_init=64, feature_transform="bf16x6"):
+               gat_softmax_group="src", d_init=64, feature_transform="f16x3"):
     """Reproduce the flag values and layer list of src/config.py for ``model``.
     Defaults are the reference's (config.py:96,126-131,180,237-238)."""
     if model not in MODELS:
@@ -149,8 +149,10 @@ def make_flags(model="higher_level_gnn", dataset="drugbank", lower_level_gnn_typ
     f.pair_interaction = False
     f.gat_softmax_group = gat_softmax_group     # SURVEY section 8c(5); not a reference flag
     # how the fused GIN layer runs its two dense transforms (not a reference flag):
-    #   "bf16x6": bf16 matrix cores, operands split in three pieces, fp32-equivalent accuracy
-    #   "f32":    exact-f32 MFMA (v_mfma_f32_32x32x2_f32), 2.7x more matrix-core time
+    #   "f16x3":  fp16 matrix cores, operands range-normalised and split in two pieces (three MFMAs per
+    #             product), fp32-equivalent accuracy; falls back to bf16x6 where the kernel has no f16 variant
+    #   "bf16x6": bf16 matrix cores, operands split in three pieces (six MFMAs), fp32-equivalent accuracy
+    #   "f32":    exact-f32 MFMA (v_mfma_f32_32x32x2_f32), 2.7x the matrix-core time of bf16x6
     f.feature_transform = feature_transform
     if last_lower is not None:
         f.last_lower_lyr_num = last_lower

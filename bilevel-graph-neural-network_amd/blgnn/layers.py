@@ -107,7 +107,14 @@ class NodeEmbedding(nn.Module):
                 w1 = self._cache.get("w1", lambda w: w.t().contiguous(), lin1.weight)
                 w2 = self._cache.get("w2", lambda w: w.t().contiguous(), lin2.weight)
                 eps = self._cache.get("eps", lambda e: float(e[0]), self.conv.eps)
-                if getattr(FLAGS, "feature_transform", "bf16x6") == "bf16x6" and \
+                transform = getattr(FLAGS, "feature_transform", "bf16x6")
+                if transform == "f16x3" and ops.gin_layer_h3_supported(csr, ins, ins.shape[1], self.out_dim):
+                    # dense transforms on the fp16 matrix cores at fp32 accuracy (scaled two-piece split)
+                    w1p = self._cache.get("w1h", lambda w: ops.pack_weight_h3(w.t().contiguous()), lin1.weight)
+                    w2p = self._cache.get("w2h", lambda w: ops.pack_weight_h3(w.t().contiguous()), lin2.weight)
+                    x = ops.gin_layer_h3(csr, ins, w1p, lin1.bias, w2p, lin2.bias, self.out_dim, eps=eps,
+                                         act=act, act_param=slopes, bn_scale=scale, bn_shift=shift, out=out)
+                elif transform in ("bf16x6", "f16x3") and \
                         ops.gin_layer_x6_supported(csr, ins, ins.shape[1], self.out_dim):
                     # dense transforms on the bf16 matrix cores at fp32 accuracy (three-piece split)
                     w1p = self._cache.get("w1p", lambda w: ops.pack_weight_x6(w.t().contiguous()), lin1.weight)

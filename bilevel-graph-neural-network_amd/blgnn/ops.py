@@ -16,7 +16,7 @@ from .config import FLAGS
 __all__ = [
     "CSR", "csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear",
     "gat_conv", "gcn_conv", "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum",
-    "row_degree", "link_pred_head", "pack_weight_x6", "linear_x6_supported", "gin_layer_x6", "gin_layer_x6_supported", "gin_stack", "molecule_tiles", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
+    "row_degree", "link_pred_head", "pack_weight_x6", "pack_weight_h3", "gin_layer_h3", "gin_layer_h3_supported", "linear_x6_supported", "gin_layer_x6", "gin_layer_x6_supported", "gin_stack", "molecule_tiles", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
     "require_device",
 ]
 
@@ -159,6 +159,34 @@ def pack_weight_x6(w_kn):
     return out
 
 
+def pack_weight_h3(w_kn):
+    """[K, N] fp32 weights -> the scaled two-piece fp16 image the f16x3 kernels read."""
+    wp, ldw = _mat(w_kn, "w")
+    K, N = w_kn.shape
+    out = torch.empty(int(_lib.load().blgnn_packed_weight_h3_elems(K, N)), dtype=torch.float16,
+                      device=w_kn.device)
+    call("blgnn_pack_weight_h3", wp, ldw, K, N, out.data_ptr(), _stream())
+    return out
+
+
+def gin_layer_h3_supported(csr, x, K, N):
+    return (N == 128 and K % 4 == 0 and K <= 128 and x.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0 and csr.nnz < 12 * max(csr.n, 1))
+
+
+def gin_layer_h3(csr, x, w1_packed, b1, w2_packed, b2, N, eps=0.0, act="identity", act_param=None,
+                 bn_scale=None, bn_shift=None, out=None):
+    """blgnn_gin_layer with both GEMMs on the fp16 matrix cores at fp32 accuracy (f16x3)."""
+    xp, ldx = _mat(x, "x")
+    n, K = x.shape
+    y = _out(out, n, N, x)
+    yp, ldy = _mat(y, "out")
+    call("blgnn_gin_layer_h3", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, xp, ldx, n, K,
+         w1_packed.data_ptr(), _vec(b1, "b1"), w2_packed.data_ptr(), _vec(b2, "b2"), N, float(eps), _act(act),
+         _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), yp, ldy, _stream())
+    return y
+
+
 def gin_layer_x6_supported(csr, x, K, N):
     return (N in (128, 256) and K % 4 == 0 and K <= 256 and x.stride(0) % 4 == 0
             and x.data_ptr() % 16 == 0 and csr.nnz < 12 * max(csr.n, 1))
@@ -267,7 +295,7 @@ def linear(x, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn
     yp, ldy = _mat(y, "out")
     if transform is None:
         transform = getattr(FLAGS, "feature_transform", "bf16x6")
-    if transform == "bf16x6" and K > 0 and N > 0 and linear_x6_supported(x, w_kn):
+    if transform in ("bf16x6", "f16x3") and K > 0 and N > 0 and linear_x6_supported(x, w_kn):
         call("blgnn_linear_x6", xp, ldx, _packed_weight(w_kn).data_ptr(), yp, ldy, M, N, K, _vec(bias, "bias"),
              _vec(rowvec, "rowvec"), _vec(rowvec_w, "rowvec_w"), _act(act), _vec(act_param, "act_param"),
              _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), _stream())

@@ -1,0 +1,498 @@
+// Fused GIN layer with the feature transform on the fp16 matrix cores at fp32 accuracy ("f16x3").
+//
+// Every fp32 operand is split into TWO fp16 pieces x = h1 + h2 (11 + 11 significand bits; the
+// representation error is 2^-23 |x|, fp32's own half-ulp) and a product a*w is the three fp16 MFMAs
+// a1*w1 + a1*w2 + a2*w1, accumulated in fp32; the dropped a2*w2 is below 2^-24 |a||w|.  Against the
+// three-piece bf16 scheme (gin_x6.hip) this is half the matrix-core work and two thirds of the
+// operand bytes in LDS and of the weight-fragment traffic (the 32-row kernels are bound by that
+// traffic: 196 KB of bf16 fragments per tile through a 64 B/clk L1 fill path), and the smaller
+// images (37 KB of LDS, 128 VGPRs) let four workgroups share a CU instead of three.
+//
+// fp16 has a 5-bit exponent, so operands are range-normalised by exact powers of two:
+//   * every activation row is scaled so that its largest magnitude lies in [2^14, 2^15) (row maximum
+//     by cross-lane reduction; the inverse is applied to the fp32 accumulators in the epilogue);
+//   * every weight matrix is scaled the same way as a whole when it is packed (blgnn_pack_weight_h3
+//     stores the inverse scale in the packed image's header).
+// Elements more than 2^13 below their row's (matrix's) maximum lose low-order bits of h2 -- an error
+// below 2^-24 of that maximum per element, i.e. of the order of fp32 rounding of the dot product.
+//
+// Structure = gin_x6.hip: stage tile -> LDS gather -> split -> GEMM -> act -> split -> GEMM ->
+// act + eval-BN -> row stores; GEMMs transposed (weight fragment = MFMA A operand) so a lane owns
+// four consecutive output columns of one row.
+#include "gin_common.hpp"
+#include "x6_common.hpp"
+
+namespace blgnn {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4h __attribute__((ext_vector_type(4)));
+
+constexpr int HCOLS = 512;       // column indices of a tile kept in LDS (64 rows x mean degree 2.1 = 136)
+constexpr int HHDR = 8;          // packed image header, in fp16 elements (16 bytes): float inv_scale
+
+struct Split2 { _Float16 h1, h2; };
+__device__ __forceinline__ Split2 split2(float x) {
+    Split2 s;
+    s.h1 = (_Float16)x;
+    s.h2 = (_Float16)(x - (float)s.h1);
+    return s;
+}
+
+// power-of-two scale that moves a magnitude into [2^14, 2^15); returns (scale, 1 / scale)
+__device__ __forceinline__ void pow2_scale(float amax, float &scale, float &inv) {
+    unsigned e = (__float_as_uint(amax) >> 23) & 0xffu;          // biased exponent of the maximum
+    e = e < 32u ? 32u : (e > 222u ? 222u : e);                   // zeros / denormals / overflow guard
+    scale = __uint_as_float((268u - e) << 23);                    // 2^(14 - (e - 127))
+    inv = __uint_as_float((e - 14u) << 23);                       // 2^((e - 127) - 14)
+}
+
+// ---- weight packing: W[K,N] fp32 -> header + [2][Kp/8][N][8] fp16, scaled by a power of two -------------
+__global__ void k_absmax(const float *__restrict__ w, int64_t ldw, int K, int N, unsigned *out) {
+    float m = 0.f;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < (int64_t)K * N;
+         idx += (int64_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(w[(idx / N) * ldw + idx % N]));
+    m = group_max(m, WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0) atomicMax(out, __float_as_uint(m));   // non-negative floats order as uints
+}
+
+__global__ void k_pack_h3(const float *__restrict__ w, int64_t ldw, int K, int N, int Kp,
+                          const unsigned *__restrict__ amax_bits, _Float16 *__restrict__ out) {
+    float scale, inv;
+    pow2_scale(__uint_as_float(*amax_bits), scale, inv);
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;          // (kb, n)
+    if (idx == 0) *reinterpret_cast<float *>(out) = inv;
+    const int kb = idx / N, n = idx - kb * N;
+    if (kb >= Kp / 8) return;
+    f16x8 p[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = kb * 8 + j;
+        const Split2 s = split2(k < K ? w[(int64_t)k * ldw + n] * scale : 0.f);
+        p[0][j] = s.h1; p[1][j] = s.h2;
+    }
+    const size_t piece = (size_t)(Kp / 8) * N;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        *reinterpret_cast<f16x8 *>(out + HHDR + ((size_t)q * piece + (size_t)kb * N + n) * 8) = p[q];
+}
+
+struct GinH3Args {
+    const int32_t *rowptr, *col;
+    const float *x; int64_t ldx;
+    int32_t n, K, Kp;                        // Kp = K padded to 32
+    const _Float16 *w1p, *w2p;               // packed images (header + pieces)
+    const float *b1, *b2;
+    float self_coef;
+    Epilogue epi;
+    float *y; int64_t ldy;
+};
+
+typedef __amdgpu_buffer_rsrc_t hrsrc_t;
+__device__ __forceinline__ hrsrc_t h3_rsrc(const _Float16 *Wp, int Kp, int N) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(Wp), 0, HHDR * 2 + 2 * Kp * N * 2, 0x00020000);
+}
+
+// Weight fragments of one 32-deep chunk: [step][piece].  Lane (fi, fh) holds the 8 consecutive k of
+// output column n_base + fi (the MFMA A operand).  Buffer addressing: one per-lane VGPR offset +
+// a wave-uniform SGPR offset per load.
+__device__ __forceinline__ void load_b_h3(f16x8 (&dst)[2][2], hrsrc_t W, int Kp, int kc, unsigned lane_off) {
+    constexpr int N = 128;
+    const unsigned piece = (unsigned)Kp * N * 2u;                 // bytes
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const unsigned soff = HHDR * 2u + (unsigned)q * piece + (unsigned)(kc / 8 + 2 * s) * (N * 16u);
+            const u32x4h v = __builtin_amdgcn_raw_buffer_load_b128(W, lane_off, soff, 0);
+            dst[s][q] = __builtin_bit_cast(f16x8, v);
+        }
+}
+
+constexpr int HRING = 3;         // weight chunk buffers (16 VGPRs each), two chunks ahead of the MFMAs
+
+__device__ __forceinline__ void h3_prefetch(f16x8 (&w)[HRING][2][2], hrsrc_t Wp, int Kp, unsigned lane_off) {
+#pragma unroll
+    for (int u = 0; u < HRING - 1; ++u)
+        if (u * KC < Kp) load_b_h3(w[u], Wp, Kp, u * KC, lane_off);
+}
+
+// acc0 += w1.a1 ; acc1 += w1.a2 + w2.a1, for both 32-row halves of the tile (transposed GEMM: the
+// lane ends up with n = n_base + 8 (r >> 2) + 4 fh + (r & 3), m = 32 mt + fi)
+template <int MT>
+__device__ __forceinline__ void gemm_h3(f32x16 (&acc0)[MT], f32x16 (&acc1)[MT], const char *Ap, int sa, hrsrc_t Wp,
+                                        int Kp, unsigned lane_off, int fi, int fh, f16x8 (&w)[HRING][2][2]) {
+    const int piece_bytes = MT * 32 * sa;
+    const char *arow = Ap + fi * sa + fh * 16;                   // lane (row fi, k half fh)
+    for (int kc = 0; kc < Kp; kc += HRING * KC) {
+#pragma unroll
+        for (int u = 0; u < HRING; ++u) {
+            const int k = kc + u * KC;
+            if (k < Kp) {
+                if (k + (HRING - 1) * KC < Kp) load_b_h3(w[(u + HRING - 1) % HRING], Wp, Kp, k + (HRING - 1) * KC, lane_off);
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const f16x8 a1 = *reinterpret_cast<const f16x8 *>(arow + mt * 32 * sa + (k + 16 * s) * 2);
+                        const f16x8 a2 = *reinterpret_cast<const f16x8 *>(arow + mt * 32 * sa + piece_bytes + (k + 16 * s) * 2);
+                        acc0[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[u][s][0], a1, acc0[mt], 0, 0, 0);
+                        acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[u][s][0], a2, acc1[mt], 0, 0, 0);
+                        acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[u][s][1], a1, acc1[mt], 0, 0, 0);
+                    }
+            }
+        }
+    }
+}
+
+// XBM rows per workgroup: 32 (four workgroups per CU) is what is launched; 64 (two per CU, every
+// weight fragment serves two row tiles) is kept as a template parameter only.
+template <int LG, int ACT, int XBM>
+__global__ void __launch_bounds__(256, XBM == 64 ? 2 : 4) k_gin_layer_h3(const GinH3Args A) {
+    constexpr int N = 128, MT = XBM / 32;
+    constexpr int RPW = WAVE / LG;
+    constexpr int PASSES = XBM / (4 * RPW);
+    constexpr int LDO = N + 4;
+    constexpr int SH = N * 2 + 16;                  // hidden piece row stride (bytes)
+    constexpr int NCV = HCOLS / 256;
+    constexpr int N4 = N / 4;
+    extern __shared__ float4 lds4[];
+    char *lds = reinterpret_cast<char *>(lds4);
+    const int sa = A.Kp * 2 + 16;                   // aggregated piece row stride (bytes)
+    // region 0: aggregated pieces [2][XBM][sa], later the fp32 output staging tile [XBM][N+4]
+    // region 1: staged fp32 input rows [XBM][K], later the hidden pieces [2][XBM][SH]
+    int r0 = 2 * XBM * sa;
+    if (XBM * LDO * 4 > r0) r0 = XBM * LDO * 4;
+    int r1 = XBM * A.K * 4;
+    if (2 * XBM * SH > r1) r1 = 2 * XBM * SH;
+    char *Ap = lds;
+    float *Ys = reinterpret_cast<float *>(lds);
+    float *Xs = reinterpret_cast<float *>(lds + r0);
+    char *Hp = lds + r0;
+    int *rp = reinterpret_cast<int *>(lds + r0 + r1);       // [XBM + 4]
+    int *cs = rp + XBM + 4;                                 // [HCOLS]
+    float *ainv = reinterpret_cast<float *>(cs + HCOLS);    // [XBM] 1 / row scale of the aggregate
+    unsigned *hmax = reinterpret_cast<unsigned *>(ainv + XBM);   // [XBM] row maxima of the hidden tile (float bits)
+    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+    const int fi = lane & 31, fh = lane >> 5;
+    const int sub = lane / LG, l = lane % LG;
+    const int n_base = wid * 32;
+    const hrsrc_t W1 = h3_rsrc(A.w1p, A.Kp, N), W2 = h3_rsrc(A.w2p, N, N);
+    const unsigned lane_off = ((unsigned)fh * N + (unsigned)(n_base + fi)) * 16u;
+    const int k4n = A.K >> 2;
+    const bool ok = l < k4n;
+    const float4 *__restrict__ X = reinterpret_cast<const float4 *>(A.x);
+    const int64_t ldx4 = A.ldx >> 2;
+    const int m0 = blockIdx.x * XBM;
+    const bool vec_out = (A.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(A.y) & 15u) == 0);
+
+    // ---- (0) requests: rowptr slice, feature rows, weight chunks, edge range -> column indices ---------------
+    int rpv = 0;
+    if (threadIdx.x <= XBM) {
+        const int r = m0 + threadIdx.x;
+        rpv = A.rowptr[r < A.n ? r : A.n];
+    }
+    float4 xin[PASSES];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int row = m0 + (p * 4 + wid) * RPW + sub;
+        xin[p] = (ok && row < A.n) ? X[(int64_t)row * ldx4 + l] : f4_zero();
+    }
+    f16x8 wfrag[HRING][2][2];
+    h3_prefetch(wfrag, W1, A.Kp, lane_off);
+    const float w1inv = *reinterpret_cast<const float *>(A.w1p), w2inv = *reinterpret_cast<const float *>(A.w2p);
+    const int e_lo = A.rowptr[m0];                                   // uniform addresses: scalar loads
+    const int ncol_all = A.rowptr[m0 + XBM < A.n ? m0 + XBM : A.n] - e_lo;
+    const bool cols_in_lds = ncol_all <= HCOLS;
+    int cv[NCV];
+#pragma unroll
+    for (int i = 0; i < NCV; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        cv[i] = (cols_in_lds && idx < ncol_all) ? A.col[e_lo + idx] : 0;
+    }
+    if (threadIdx.x <= XBM) rp[threadIdx.x] = rpv;
+    if (threadIdx.x < XBM) hmax[threadIdx.x] = 0u;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int m = (p * 4 + wid) * RPW + sub;
+        if (ok) *reinterpret_cast<float4 *>(Xs + m * A.K + 4 * l) = xin[p];
+    }
+#pragma unroll
+    for (int i = 0; i < NCV; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        if (cols_in_lds && idx < ncol_all) cs[idx] = cv[i];
+    }
+    // zero the K padding columns of the two aggregated pieces
+    for (int idx = threadIdx.x; idx < 2 * XBM * (A.Kp - A.K); idx += 256) {
+        const int per = XBM * (A.Kp - A.K);
+        const int q = idx / per, rem = idx - q * per;
+        const int m = rem / (A.Kp - A.K), k = A.K + rem % (A.Kp - A.K);
+        *reinterpret_cast<_Float16 *>(Ap + q * XBM * sa + m * sa + k * 2) = (_Float16)0.f;
+    }
+    lds_barrier();
+
+    // ---- (1) gather from LDS (+ out-of-tile rows from L2, FB passes per round trip), scale, split, park --------
+    constexpr int FBMAX = XBM == 64 ? 4 : 2;       // 16 VGPRs per pass in flight
+    constexpr int FB = PASSES < FBMAX ? PASSES : FBMAX;
+#pragma unroll
+    for (int pg = 0; pg < PASSES; pg += FB) {
+        float4 accv[FB];
+        int far[FB][4];
+#pragma unroll
+        for (int pp = 0; pp < FB; ++pp) {
+            const int m = ((pg + pp) * 4 + wid) * RPW + sub;
+            const int row = m0 + m;
+            const int e0 = rp[m], cnt = rp[m + 1] - e0;
+            const int lo4 = ok ? 4 * l : 0;
+            accv[pp] = *reinterpret_cast<const float4 *>(Xs + m * A.K + lo4);
+            accv[pp].x *= A.self_coef; accv[pp].y *= A.self_coef;
+            accv[pp].z *= A.self_coef; accv[pp].w *= A.self_coef;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int ci = e0 + q - e_lo;
+                ci = (q < cnt && ci < HCOLS) ? ci : 0;
+                const int c = cs[ci];
+                const int j = (q < cnt && cols_in_lds) ? c : row;
+                const int jl = j - m0;
+                const bool in_tile = jl >= 0 && jl < XBM;
+                far[pp][q] = (in_tile || !ok) ? -1 : j;
+                const bool use = in_tile && j != row;
+                const float4 u = *reinterpret_cast<const float4 *>(Xs + (use ? jl : m) * A.K + lo4);
+                f4_fma(accv[pp], use ? 1.f : 0.f, u);
+            }
+        }
+        float4 fu[FB][4];
+#pragma unroll
+        for (int pp = 0; pp < FB; ++pp)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                fu[pp][q] = f4_zero();
+                if (far[pp][q] >= 0) fu[pp][q] = X[(int64_t)far[pp][q] * ldx4 + l];
+            }
+#pragma unroll
+        for (int pp = 0; pp < FB; ++pp) {
+            const int m = ((pg + pp) * 4 + wid) * RPW + sub;
+            const int row = m0 + m;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f4_add(accv[pp], fu[pp][q]);
+            if (ok) {
+                const int e0 = rp[m], cnt = rp[m + 1] - e0;
+                const int first = cols_in_lds ? 4 : 0;
+                for (int e = e0 + first; e < e0 + cnt; ++e) {
+                    const int jj = A.col[e];
+                    if (jj != row) f4_add(accv[pp], X[(int64_t)jj * ldx4 + l]);
+                }
+            }
+            // row maximum over the LG lanes of the row -> power-of-two scale
+            float amax = ok ? fmaxf(fmaxf(fabsf(accv[pp].x), fabsf(accv[pp].y)), fmaxf(fabsf(accv[pp].z), fabsf(accv[pp].w))) : 0.f;
+#pragma unroll
+            for (int off = 1; off < LG; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off, WAVE));
+            float scale, inv;
+            pow2_scale(amax, scale, inv);
+            if (l == 0) ainv[m] = inv;
+            if (ok) {
+                const Split2 s0 = split2(accv[pp].x * scale), s1 = split2(accv[pp].y * scale),
+                             s2 = split2(accv[pp].z * scale), s3 = split2(accv[pp].w * scale);
+                f16x4 h1 = {s0.h1, s1.h1, s2.h1, s3.h1}, h2 = {s0.h2, s1.h2, s2.h2, s3.h2};
+                char *dst = Ap + m * sa + 8 * l;
+                *reinterpret_cast<f16x4 *>(dst) = h1;
+                *reinterpret_cast<f16x4 *>(dst + XBM * sa) = h2;
+            }
+        }
+    }
+    lds_barrier();
+
+    // ---- (2) hidden = act(agg @ W1 + b1): row maxima -> scale -> split -> park -----------------------------------
+    f32x16 acc0[MT], acc1[MT];
+    auto zero = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[mt][r] = 0.f; acc1[mt][r] = 0.f; }
+    };
+    zero();
+    float4 pb[4], psl[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c = n_base + 8 * g + 4 * fh;             // four consecutive output columns
+        pb[g] = A.b1 ? *reinterpret_cast<const float4 *>(A.b1 + c) : f4_zero();
+        psl[g] = (ACT == BLGNN_ACT_PRELU && A.epi.act_param) ? *reinterpret_cast<const float4 *>(A.epi.act_param + c)
+                                                            : f4_zero();
+    }
+    gemm_h3<MT>(acc0, acc1, Ap, sa, W1, A.Kp, lane_off, fi, fh, wfrag);
+    h3_prefetch(wfrag, W2, N, lane_off);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const float rs = ainv[mt * 32 + fi] * w1inv;
+        float hm = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 v;
+            v.x = act_t<ACT>(fmaf(acc0[mt][4 * g + 0] + acc1[mt][4 * g + 0], rs, pb[g].x), psl[g].x);
+            v.y = act_t<ACT>(fmaf(acc0[mt][4 * g + 1] + acc1[mt][4 * g + 1], rs, pb[g].y), psl[g].y);
+            v.z = act_t<ACT>(fmaf(acc0[mt][4 * g + 2] + acc1[mt][4 * g + 2], rs, pb[g].z), psl[g].z);
+            v.w = act_t<ACT>(fmaf(acc0[mt][4 * g + 3] + acc1[mt][4 * g + 3], rs, pb[g].w), psl[g].w);
+            acc0[mt][4 * g + 0] = v.x; acc0[mt][4 * g + 1] = v.y; acc0[mt][4 * g + 2] = v.z; acc0[mt][4 * g + 3] = v.w;
+            hm = fmaxf(hm, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+        hm = fmaxf(hm, __shfl_xor(hm, 32, WAVE));           // the row's other 16 columns of this wave
+        if (fh == 0) atomicMax(&hmax[mt * 32 + fi], __float_as_uint(hm));   // across the four column waves
+    }
+    lds_barrier();
+    float hinv[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        float scale;
+        pow2_scale(__uint_as_float(hmax[mt * 32 + fi]), scale, hinv[mt]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = n_base + 8 * g + 4 * fh;
+            const Split2 s0 = split2(acc0[mt][4 * g + 0] * scale), s1 = split2(acc0[mt][4 * g + 1] * scale),
+                         s2 = split2(acc0[mt][4 * g + 2] * scale), s3 = split2(acc0[mt][4 * g + 3] * scale);
+            f16x4 h1 = {s0.h1, s1.h1, s2.h1, s3.h1}, h2 = {s0.h2, s1.h2, s2.h2, s3.h2};
+            char *dst = Hp + (mt * 32 + fi) * SH + c * 2;
+            *reinterpret_cast<f16x4 *>(dst) = h1;
+            *reinterpret_cast<f16x4 *>(dst + XBM * SH) = h2;
+        }
+    }
+    lds_barrier();
+
+    // ---- (3) y = affine(act(hidden @ W2 + b2)) -> LDS staging -> row stores ---------------------------------
+    zero();
+    float4 psc[4], psh[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c = n_base + 8 * g + 4 * fh;
+        pb[g] = A.b2 ? *reinterpret_cast<const float4 *>(A.b2 + c) : f4_zero();
+        psc[g] = float4{1.f, 1.f, 1.f, 1.f};
+        psh[g] = f4_zero();
+        if (A.epi.bn_scale) psc[g] = *reinterpret_cast<const float4 *>(A.epi.bn_scale + c);
+        if (A.epi.bn_scale && A.epi.bn_shift) psh[g] = *reinterpret_cast<const float4 *>(A.epi.bn_shift + c);
+    }
+    gemm_h3<MT>(acc0, acc1, Hp, SH, W2, N, lane_off, fi, fh, wfrag);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const float rs = hinv[mt] * w2inv;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = n_base + 8 * g + 4 * fh;
+            float4 v;
+            v.x = act_t<ACT>(fmaf(acc0[mt][4 * g + 0] + acc1[mt][4 * g + 0], rs, pb[g].x), psl[g].x);
+            v.y = act_t<ACT>(fmaf(acc0[mt][4 * g + 1] + acc1[mt][4 * g + 1], rs, pb[g].y), psl[g].y);
+            v.z = act_t<ACT>(fmaf(acc0[mt][4 * g + 2] + acc1[mt][4 * g + 2], rs, pb[g].z), psl[g].z);
+            v.w = act_t<ACT>(fmaf(acc0[mt][4 * g + 3] + acc1[mt][4 * g + 3], rs, pb[g].w), psl[g].w);
+            if (A.epi.bn_scale) {
+                v.x = fmaf(v.x, psc[g].x, psh[g].x); v.y = fmaf(v.y, psc[g].y, psh[g].y);
+                v.z = fmaf(v.z, psc[g].z, psh[g].z); v.w = fmaf(v.w, psc[g].w, psh[g].w);
+            }
+            *reinterpret_cast<float4 *>(Ys + (mt * 32 + fi) * LDO + c) = v;
+        }
+    }
+    lds_barrier();
+    for (int idx = threadIdx.x; idx < XBM * N4; idx += 256) {
+        const int m = idx / N4, c4 = idx % N4;
+        const int row = m0 + m;
+        if (row >= A.n) continue;
+        const float4 v = *reinterpret_cast<const float4 *>(Ys + m * LDO + 4 * c4);
+        float *dst = A.y + (int64_t)row * A.ldy + 4 * c4;
+        if (vec_out) *reinterpret_cast<float4 *>(dst) = v;
+        else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
+    }
+}
+
+static size_t h3_lds_bytes(int K, int Kp, int XBM) {
+    const int N = 128;
+    size_t r0 = (size_t)2 * XBM * (Kp * 2 + 16);
+    if ((size_t)XBM * (N + 4) * 4 > r0) r0 = (size_t)XBM * (N + 4) * 4;
+    size_t r1 = (size_t)XBM * K * 4;
+    if ((size_t)2 * XBM * (N * 2 + 16) > r1) r1 = (size_t)2 * XBM * (N * 2 + 16);
+    return r0 + r1 + sizeof(int) * (XBM + 4 + HCOLS) + sizeof(float) * 2 * XBM;
+}
+
+template <int LG, int ACT, int XBM>
+static int launch_h3_rows(const GinH3Args &A, hipStream_t s) {
+    static size_t declared = 0;
+    const size_t bytes = h3_lds_bytes(A.K, A.Kp, XBM);
+    if (bytes > declared && bytes > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gin_layer_h3<LG, ACT, XBM>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+            return fail(BLGNN_ERR_LAUNCH, "gin_layer_h3: cannot raise the dynamic LDS limit to %zu bytes", bytes);
+        declared = bytes;
+    }
+    const int blocks = (A.n + XBM - 1) / XBM;
+    hipLaunchKernelGGL((k_gin_layer_h3<LG, ACT, XBM>), dim3(blocks), dim3(256), bytes, s, A);
+    return launch_status("gin_layer_h3");
+}
+
+template <int LG, int ACT>
+static int launch_h3(const GinH3Args &A, hipStream_t s) {
+    // 32-row workgroups, four per CU.  (64-row workgroups at two per CU -- every weight fragment
+    // serving two row tiles -- measured the same on 471 k rows, 264 vs 259 us, and worse on graphs
+    // that do not fill two rounds of them: 31.5 vs 24.3 us on 36 k rows.)
+    return launch_h3_rows<LG, ACT, 32>(A, s);
+}
+
+template <int LG>
+static int h3_pick_act(const GinH3Args &A, hipStream_t s) {
+    switch (A.epi.act) {
+        case BLGNN_ACT_RELU:    return launch_h3<LG, BLGNN_ACT_RELU>(A, s);
+        case BLGNN_ACT_PRELU:   return launch_h3<LG, BLGNN_ACT_PRELU>(A, s);
+        case BLGNN_ACT_SIGMOID: return launch_h3<LG, BLGNN_ACT_SIGMOID>(A, s);
+        case BLGNN_ACT_TANH:    return launch_h3<LG, BLGNN_ACT_TANH>(A, s);
+        default:                return launch_h3<LG, BLGNN_ACT_IDENTITY>(A, s);
+    }
+}
+
+}  // namespace blgnn
+
+using namespace blgnn;
+
+extern "C" int64_t blgnn_packed_weight_h3_elems(int32_t K, int32_t N) {
+    const int64_t Kp = ((int64_t)K + 31) / 32 * 32;
+    return HHDR + 2 * Kp * N;                             // fp16 elements
+}
+
+extern "C" int blgnn_pack_weight_h3(const float *w, int64_t ldw, int32_t K, int32_t N, void *out, void *stream) {
+    BLGNN_CHECK_ARG(w && out && K > 0 && N > 0 && ldw >= N, "pack_weight_h3: bad args");
+    BLGNN_CHECK_ARG(aligned16(out), "pack_weight_h3: out must be 16-byte aligned");
+    const int Kp = (K + 31) / 32 * 32;
+    hipStream_t s = (hipStream_t)stream;
+    // header word 1 is scratch for the absolute maximum (float bits), word 0 receives 1 / scale
+    unsigned *amax = reinterpret_cast<unsigned *>(out) + 1;
+    if (hipMemsetAsync(out, 0, HHDR * 2, s) != hipSuccess) return fail(BLGNN_ERR_LAUNCH, "pack_weight_h3: memset failed");
+    const int64_t total = (int64_t)K * N;
+    hipLaunchKernelGGL(k_absmax, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)), dim3(256), 0, s,
+                       w, ldw, K, N, amax);
+    const int64_t items = (int64_t)(Kp / 8) * N;
+    hipLaunchKernelGGL(k_pack_h3, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, w, ldw, K, N, Kp, amax,
+                       reinterpret_cast<_Float16 *>(out));
+    return launch_status("pack_weight_h3");
+}
+
+extern "C" int blgnn_gin_layer_h3(const int32_t *rowptr, const int32_t *col, int64_t nnz, const float *x,
+                                  int64_t ldx, int32_t n, int32_t K, const void *w1_packed, const float *b1,
+                                  const void *w2_packed, const float *b2, int32_t N, float eps, int32_t act,
+                                  const float *act_param, const float *bn_scale, const float *bn_shift,
+                                  float *y, int64_t ldy, void *stream) {
+    BLGNN_CHECK_ARG(n >= 0 && K > 0 && N > 0 && nnz >= 0, "gin_layer_h3: bad sizes");
+    if (n == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(rowptr && (col || nnz == 0) && x && w1_packed && w2_packed && y, "gin_layer_h3: null pointer");
+    BLGNN_CHECK_ARG(ldx >= K && ldy >= N, "gin_layer_h3: leading dimension too small");
+    BLGNN_CHECK_ARG(act >= 0 && act <= BLGNN_ACT_TANH, "gin_layer_h3: bad activation id");
+    BLGNN_CHECK_ARG(x != y, "gin_layer_h3: x and y must not alias");
+    if (N != 128 || K % 4 != 0 || K > 128 || ldx % 4 != 0 || !aligned16(x) || !aligned16(w1_packed) ||
+        !aligned16(w2_packed))
+        return fail(BLGNN_ERR_UNSUPPORTED, "gin_layer_h3: needs N == 128, K %% 4 == 0, K <= 128 and 16-byte aligned x / "
+                    "packed weights (got N=%d K=%d); use blgnn_gin_layer_x6", N, K);
+    GinH3Args A;
+    A.rowptr = rowptr; A.col = col; A.x = x; A.ldx = ldx; A.n = n; A.K = K; A.Kp = (K + 31) / 32 * 32;
+    A.w1p = reinterpret_cast<const _Float16 *>(w1_packed); A.w2p = reinterpret_cast<const _Float16 *>(w2_packed);
+    A.b1 = b1; A.b2 = b2; A.self_coef = 1.f + eps;
+    A.epi = Epilogue{b2, act_param, bn_scale, bn_shift, act};
+    A.y = y; A.ldy = ldy;
+    hipStream_t s = (hipStream_t)stream;
+    const int k4 = K / 4;
+    if (k4 <= 16) return h3_pick_act<16>(A, s);
+    return h3_pick_act<32>(A, s);
+}

@@ -125,6 +125,23 @@ int blgnn_gin_layer_x6(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                        const float *act_param, const float *bn_scale,
                        const float *bn_shift, float *y, int64_t ldy, void *stream);
 
+/* Same layer on the fp16 matrix cores at fp32 accuracy ("f16x3": operands split in TWO fp16
+ * pieces, three MFMAs per product; activation rows and weight matrices range-normalised by
+ * exact powers of two).  Half the matrix-core work and two thirds of the operand bytes of the
+ * bf16x6 variant; 64-row tiles.  w*_packed = blgnn_pack_weight_h3 images
+ * (blgnn_packed_weight_h3_elems fp16 elements each, 16-byte aligned: 16-byte header holding
+ * 1/scale, then [2 pieces][Kp/8][N][8]).  N == 128, K % 4 == 0, K <= 128, else
+ * BLGNN_ERR_UNSUPPORTED (use blgnn_gin_layer_x6). */
+int64_t blgnn_packed_weight_h3_elems(int32_t K, int32_t N);
+int blgnn_pack_weight_h3(const float *w, int64_t ldw, int32_t K, int32_t N, void *out,
+                         void *stream);
+int blgnn_gin_layer_h3(const int32_t *rowptr, const int32_t *col, int64_t nnz,
+                       const float *x, int64_t ldx, int32_t n, int32_t K,
+                       const void *w1_packed, const float *b1, const void *w2_packed,
+                       const float *b2, int32_t N, float eps, int32_t act,
+                       const float *act_param, const float *bn_scale,
+                       const float *bn_shift, float *y, int64_t ldy, void *stream);
+
 /* The whole lower level in ONE launch: num_layers (<= 8) stacked GIN NodeEmbedding layers
  * (model/layers.py:26-31,51-57) + the node -> graph readout of every layer that is pooled
  * (model/layers_aggregation.py:27-42, multi-scale concat = one column slice per layer).

@@ -86,6 +86,10 @@ def gin_layer(csr, x, w1_kn, b1, w2_kn, b2, eps=0.0, act="identity", act_param=N
     return _put(out, _epi(v, act, act_param, bn_scale, bn_shift))
 
 
+def gin_layer_h3_supported(csr, x, K, N):
+    return False
+
+
 def gin_layer_x6_supported(csr, x, K, N):
     return False                                   # the CPU stand-in has no packed-weight path
 

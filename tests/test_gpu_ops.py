@@ -134,6 +134,52 @@ def test_linear_epilogue(device, act):
     assert max_err(got, ref) < TOL
 
 
+@pytest.mark.parametrize("K,act", [(52, "relu"), (128, "relu"), (128, "identity"), (64, "prelu"), (40, "tanh"), (128, "sigmoid")])
+def test_gin_layer_f16x3(device, K, act):
+    """fp16 two-piece split GIN layer (64-row tiles, row / matrix power-of-two scaling) == oracle at the fp32 bar"""
+    N = 128
+    ei, _, n = molecule_graph(53, 21)                       # n is not a multiple of the 64-row tile
+    g = torch.Generator().manual_seed(K * 7 + len(act))
+    x = torch.randn(n, K, generator=g)
+    w1, b1 = torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g) * 0.1
+    w2, b2 = torch.randn(N, N, generator=g) / N ** 0.5, torch.randn(N, generator=g) * 0.1
+    slope, scale, shift = torch.rand(N, generator=g), torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    D = lambda t: t.double()
+    ref = oracle.gin_conv(D(x), ei, D(w1), D(b1), D(w2), D(b2), act, eps=0.25, prelu_weight=D(slope))
+    ref = oracle.apply_act(ref, act, D(slope)) * D(scale) + D(shift)
+    dv = lambda t: t.to(device)
+    csr = ops.csr_from_edge_index(dv(ei), n)
+    assert ops.gin_layer_h3_supported(csr, dv(x), K, N)
+    w1p, w2p = ops.pack_weight_h3(dv(w1.t().contiguous())), ops.pack_weight_h3(dv(w2.t().contiguous()))
+    wide = torch.zeros(n, N + 8, device=device)
+    got = ops.gin_layer_h3(csr, dv(x), w1p, dv(b1), w2p, dv(b2), N, eps=0.25, act=act, act_param=dv(slope),
+                           bn_scale=dv(scale), bn_shift=dv(shift), out=wide[:, 4:4 + N])
+    assert max_err(got, ref) < TOL
+    assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + N:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("xs,ws", [(1e-6, 1.0), (3e4, 1.0), (1.0, 1e-5), (1.0, 300.0), (1e5, 1e-4)])
+def test_gin_layer_f16x3_range(device, xs, ws):
+    """the power-of-two normalisation keeps the fp16 pieces in range for tiny / huge activations and weights,
+    and for rows whose entries span many orders of magnitude"""
+    N, K = 128, 128
+    ei, _, n = molecule_graph(9, 21)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, K, generator=g) * xs
+    x[::3] *= torch.logspace(-6, 0, K).view(1, -1)          # wide dynamic range inside a row
+    w1, b1 = torch.randn(N, K, generator=g) / K ** 0.5 * ws, torch.zeros(N)
+    w2, b2 = torch.randn(N, N, generator=g) / N ** 0.5 / ws, torch.zeros(N)
+    D = lambda t: t.double()
+    ref = oracle.gin_conv(D(x), ei, D(w1), D(b1), D(w2), D(b2), "relu", eps=0.0)
+    ref = oracle.apply_act(ref, "relu", None)
+    dv = lambda t: t.to(device)
+    csr = ops.csr_from_edge_index(dv(ei), n)
+    w1p, w2p = ops.pack_weight_h3(dv(w1.t().contiguous())), ops.pack_weight_h3(dv(w2.t().contiguous()))
+    got = ops.gin_layer_h3(csr, dv(x), w1p, dv(b1), w2p, dv(b2), N, act="relu")
+    assert bool(torch.isfinite(got).all())
+    assert float((got.cpu().double() - ref).abs().max() / ref.abs().max()) < TOL
+
+
 @pytest.mark.parametrize("M,N,K", [(32768, 128, 128), (33001, 64, 52), (32800, 100, 36), (11000, 300, 260),
                                    (32769, 1, 8), (16500, 256, 1024)])
 def test_linear_bf16x6_shapes(device, M, N, K):
