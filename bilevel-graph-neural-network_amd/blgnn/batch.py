@@ -141,10 +141,19 @@ class BatchData(object):
         rows = getattr(self, "_graph_rows", None)
         if rows is None:
             gs_map = self.dataset.gs_map
-            rows = torch.as_tensor(np.asarray([gs_map[g] for g in self._graph_gids], dtype=np.int32))
-            rows = rows.to(self.merge_data['merge'].x.device)
+            host = np.asarray([gs_map[g] for g in self._graph_gids], dtype=np.int32)
+            rows = torch.as_tensor(host).to(self.merge_data['merge'].x.device)
             self._graph_rows = rows
+            # contiguous ascending run of rows (a sweep over the drugs in gs_map order): the readout can
+            # write its result straight into that slice of init_x
+            self._graph_row_range = (int(host[0]), int(host[-1]) + 1) if (
+                len(host) > 0 and np.array_equal(host, np.arange(host[0], host[0] + len(host)))) else None
         return rows
+
+    def interaction_row_range(self):
+        """(lo, hi) when the batch graphs are rows lo..hi-1 of the interaction graph in order, else None."""
+        self.interaction_rows_of_batch_graphs()
+        return self._graph_row_range
 
     def true_labels(self):
         return torch.as_tensor(self._labels).to(self.merge_data['merge'].x.device)

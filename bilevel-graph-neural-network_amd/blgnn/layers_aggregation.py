@@ -50,7 +50,7 @@ class NodeAggregationPairs(nn.Module):
         else:
             raise NotImplementedError("{} is not implemented".format(style))
 
-    def forward(self, ins, batch_data, model, pair_batch=False):
+    def forward(self, ins, batch_data, model, pair_batch=False, out=None):
         ops.require_device(ins, "ins")
         seg = _segments(batch_data, pair_batch)
         with torch.no_grad():
@@ -60,7 +60,7 @@ class NodeAggregationPairs(nn.Module):
                 else:
                     xs = [x for i, x in enumerate(model.acts[1:]) if i % 2 == 1]
                 if isinstance(self.agg_func, _SegmentPool) and len(xs) <= 8:
-                    out = ops.segment_reduce_multi(seg, xs, self.agg_func.kind)
+                    out = ops.segment_reduce_multi(seg, xs, self.agg_func.kind, out=out)
                 elif isinstance(self.agg_func, _SegmentPool):
                     G = seg.numel() - 1
                     widths = [x.shape[1] for x in xs]
@@ -96,19 +96,32 @@ class NodeAggregation(NodeAggregationPairs):
         self.is_last_layer = is_last_layer
 
     def forward(self, x, batch_data, model, pair_batch=False):
-        out = super().forward(x, batch_data, model, pair_batch)
         if not FLAGS.higher_level_layers:
-            return out
-        # layers_aggregation.py:68-74: init_x[gs_map[gid]] = out[ind], as one kernel
+            return super().forward(x, batch_data, model, pair_batch)
+        # layers_aggregation.py:68-74: init_x[gs_map[gid]] = out[ind]
         graph = batch_data.interaction_combo_nxgraph
-        rows = batch_data.interaction_rows_of_batch_graphs()
         init_x = graph.init_x
+        rng = batch_data.interaction_row_range() if hasattr(batch_data, "interaction_row_range") else None
+        if rng is not None and isinstance(init_x, torch.Tensor) and self.concat_multi_scale and \
+                isinstance(self.agg_func, _SegmentPool) and init_x.shape[1] == self._pooled_width(model):
+            # the batch graphs are a contiguous run of interaction rows: the readout writes that slice
+            # of init_x directly and the returned tensor is a view of it
+            return super().forward(x, batch_data, model, pair_batch, out=init_x[rng[0]:rng[1]])
+        out = super().forward(x, batch_data, model, pair_batch)
+        rows = batch_data.interaction_rows_of_batch_graphs()
         if not isinstance(init_x, torch.Tensor) or init_x.shape[1] != out.shape[1]:
             init_x = torch.zeros((graph.number_of_nodes(), out.shape[1]), dtype=torch.float32,
                                  device=out.device)
             graph.init_x = init_x
         ops.scatter_rows(out, rows, init_x)
         return out
+
+    def _pooled_width(self, model):
+        if 'gmn' not in FLAGS.model:
+            xs = model.acts[1:]
+        else:
+            xs = [x for i, x in enumerate(model.acts[1:]) if i % 2 == 1]
+        return sum(x.shape[1] for x in xs) if len(xs) <= 8 else -1
 
 
 class GMNAggregatorPairs(nn.Module):

@@ -365,7 +365,7 @@ def segment_reduce(seg, x, kind="mean", out=None, row_map=None):
     return out
 
 
-def segment_reduce_multi(seg, xs, kind="mean", row_map=None):
+def segment_reduce_multi(seg, xs, kind="mean", row_map=None, out=None):
     """torch.cat([scatter_mean(x, batch) for x in xs], dim=1) in one launch (<= 8 inputs)."""
     import ctypes
     if not 1 <= len(xs) <= 8:
@@ -375,11 +375,12 @@ def segment_reduce_multi(seg, xs, kind="mean", row_map=None):
     for i, x in enumerate(xs):
         p, ld = _mat(x, "xs[%d]" % i)
         ptrs.append(p); lds.append(ld); ds.append(x.shape[1])
-    out = torch.empty((G, sum(ds)), dtype=torch.float32, device=xs[0].device)
+    out = _out(out, G, sum(ds), xs[0])
+    op, ldo = _mat(out, "out")
     n = len(xs)
     call("blgnn_segment_reduce_multi", _vec(seg, "seg", torch.int32, False), G, n,
          (ctypes.c_void_p * n)(*ptrs), (ctypes.c_int64 * n)(*lds), (ctypes.c_int32 * n)(*ds),
-         REDUCE_MEAN if kind == "mean" else REDUCE_SUM, out.data_ptr(), out.shape[1],
+         REDUCE_MEAN if kind == "mean" else REDUCE_SUM, op, ldo,
          _vec(row_map, "row_map", torch.int32), _stream())
     return out
 

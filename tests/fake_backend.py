@@ -121,8 +121,8 @@ def segment_reduce(seg, x, kind="mean", out=None, row_map=None):
     return out
 
 
-def segment_reduce_multi(seg, xs, kind="mean", row_map=None):
-    return torch.cat([segment_reduce(seg, x, kind) for x in xs], dim=1)
+def segment_reduce_multi(seg, xs, kind="mean", row_map=None, out=None):
+    return _put(out, torch.cat([segment_reduce(seg, x, kind) for x in xs], dim=1))
 
 
 def gmn_match(seg, x, out=None):
