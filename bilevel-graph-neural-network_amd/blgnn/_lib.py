@@ -53,6 +53,7 @@ SIGNATURES = {
     "blgnn_segment_reduce": [_p, _i32, _p, _i64, _i32, _i32, _p, _i64, _p, _p],
     "blgnn_segment_reduce_multi": [_p, _i32, _i32, _p, _p, _p, _i32, _p, _i64, _p, _p],
     "blgnn_linear": [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p, _p],
+    "blgnn_gat_transform": [_p, _i64, _p, _i64, _p, _i32, _i32, _i32, _p, _i64, _p, _p, _p],
     "blgnn_linear_x6": [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p, _p],
     "blgnn_gmn_match": [_p, _i32, _p, _i64, _p, _i64, _i32, _p],
     "blgnn_pair_gather_normalize": [_p, _i64, _p, _p, _i32, _i32, _f32, _p, _i64, _p],

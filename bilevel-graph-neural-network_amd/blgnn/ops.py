@@ -257,6 +257,7 @@ def gin_stack(csr, x0, tile_row, tile_mol, seg, layers, pooled, pool_cols, kind=
 # entry can never be matched by a different tensor that happens to reuse the address) and refreshed
 # when the tensor is written in place (_version) or moved.
 _PACKED = {}
+GAT_TRANSFORM_MAX_ROWS = 8192  # above this the transform is throughput bound: tiled GEMM + scores kernel
 LINEAR_X6_MIN_TILES = 256      # 128x128 output tiles; below one per CU the f32 kernels' smaller tiles win
 
 
@@ -311,14 +312,25 @@ def gat_conv(csr, x, weight, att, bias, group="src", slope=0.2, act="identity", 
     """GATConv(heads=1) + the caller's act / eval-BN epilogue."""
     if group not in GAT_GROUP:
         raise ValueError("softmax_group must be 'src' or 'dst'")
-    h = linear(x, weight)
-    n, d = h.shape
-    hp, ldh = _mat(h, "h")
-    stats = torch.empty((4, n), dtype=torch.float32, device=h.device)
+    n, d = x.shape[0], weight.shape[1]
+    stats = torch.empty((4, n), dtype=torch.float32, device=x.device)
     s_dst, s_src, mx, den = (stats[i].data_ptr() for i in range(4))
     attv = att.reshape(-1)
     s = _stream()
-    call("blgnn_gat_scores", hp, ldh, _vec(attv, "att", optional=False), n, d, s_dst, s_src, s)
+    if d <= 128 and n < GAT_TRANSFORM_MAX_ROWS:
+        # interaction level: x @ W and both attention halves in one split-K launch
+        xp, ldx = _mat(x, "x")
+        wp, ldw = _mat(weight, "w")
+        if weight.shape[0] != x.shape[1]:
+            raise ValueError("blgnn: x is [%d,%d] but w is [%d,%d]" % (n, x.shape[1], weight.shape[0], d))
+        h = torch.empty((n, d), dtype=torch.float32, device=x.device)
+        hp, ldh = _mat(h, "h")
+        call("blgnn_gat_transform", xp, ldx, wp, ldw, _vec(attv, "att", optional=False), n, d, x.shape[1],
+             hp, ldh, s_dst, s_src, s)
+    else:
+        h = linear(x, weight)
+        hp, ldh = _mat(h, "h")
+        call("blgnn_gat_scores", hp, ldh, _vec(attv, "att", optional=False), n, d, s_dst, s_src, s)
     call("blgnn_gat_softmax_stats", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, s_dst, s_src, n,
          GAT_GROUP[group], float(slope), mx, den, s)
     y = _out(out, n, d, h)

@@ -187,6 +187,12 @@ int blgnn_gcn_aggregate(const int32_t *rowptr, const int32_t *col, int64_t nnz,
  * Step 1: s_dst[i] = h_i . att[0:d], s_src[i] = h_i . att[d:2d]. */
 int blgnn_gat_scores(const float *h, int64_t ldh, const float *att, int32_t n,
                      int32_t d, float *s_dst, float *s_src, void *stream);
+/* Steps 0+1 in one launch for the interaction level (a few thousand rows, N <= 128):
+ * h = x[M,K] @ w[K,N] (exact-f32 MFMA, split-K over 16 wavefronts) and both attention halves
+ * of every row.  N > 128 returns BLGNN_ERR_UNSUPPORTED (use blgnn_linear + blgnn_gat_scores). */
+int blgnn_gat_transform(const float *x, int64_t ldx, const float *w, int64_t ldw,
+                        const float *att, int32_t M, int32_t N, int32_t K, float *h,
+                        int64_t ldh, float *s_dst, float *s_src, void *stream);
 /* Step 2: per softmax group g: mx[g] = max_e a_e, den[g] = sum_e exp(a_e - mx[g]),
  * a_e = leaky_relu(s_dst[target] + s_src[source], slope) over the edges of the
  * group plus the appended self loop; existing self loops are dropped.
