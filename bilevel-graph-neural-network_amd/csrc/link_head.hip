@@ -7,6 +7,7 @@
 // as separate GEMM launches it is three grids of mostly idle 32x32 MFMA tiles plus a gather
 // kernel plus two index copies; fused it is one short launch.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace blgnn {
 
@@ -124,6 +125,152 @@ __global__ void __launch_bounds__(256) k_link_head(const HeadArgs A) {
     }
 }
 
+
+// ---- matrix-core variant: 32 pairs per workgroup -----------------------------------------------------------
+// For embedding widths up to 256 (first layer 2d <= 512 wide, <= 128 outputs) the head is re-blocked
+// around the first layer, which holds 98 % of its flops: a workgroup gathers and normalises the rows of 32
+// pairs into LDS (all 64 row loads of a wave in flight together instead of one dependent chain per
+// pair), runs  [32 x 2d] @ W1  on v_mfma_f32_32x32x2_f32 with K split over its four waves and the
+// weights read straight from L2 (each element once per 32 pairs, not once per 4), and finishes the
+// narrow tail layers with one thread per (pair, output).
+typedef float f32x16h __attribute__((ext_vector_type(16)));
+constexpr int HP = 32;                      // pairs per workgroup
+constexpr int HK_MAX = 512;                 // first-layer input width (2 d)
+constexpr int HN_MAX = 128;                 // first-layer output width
+
+// One wave's share of the first layer: acc[t] += X[:, k] (x) W1[k, 32 t .. 32 t + 31] over kq k's.
+// The weight operands come straight from L2 (a ~1.5 k-cycle round trip): 16 k-steps are unrolled so
+// their loads are all requested before the first MFMA of the batch needs one.
+template <int NT>
+__device__ __forceinline__ void first_layer_tiles(const float *xa, const float *wb, int kq, int N1, int fi, int fh,
+                                                  float *dst, int ldh) {
+    f32x16h acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    bool in[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) in[t] = 32 * t + fi < N1;
+    for (int k0 = 0; k0 < kq; k0 += 32) {
+        float b[16][NT];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                b[u][t] = (in[t] && k0 + 2 * u < kq) ? wb[(int64_t)(k0 + 2 * u) * N1 + 32 * t] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const float a = k0 + 2 * u < kq ? xa[k0 + 2 * u] : 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[u][t], acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+            dst[row * ldh + 32 * t + fi] = acc[t][r];
+        }
+}
+
+__device__ __forceinline__ const float *wfrag_base(const HeadArgs &A, int wid, int fh, int fi) {
+    return A.w[0] + (int64_t)(wid * (A.dims[0] >> 2) + fh) * A.dims[1] + fi;
+}
+
+__global__ void __launch_bounds__(256) k_link_head_mfma(const HeadArgs A) {
+    extern __shared__ float lds[];
+    const int K0 = A.dims[0], N1 = A.dims[1];
+    const int ldx = K0 + 1;                              // odd stride: conflict-free A-operand reads
+    float *X = lds;                                      // [HP][K0 + 1] normalised, concatenated rows
+    const int ldh = A.width + 1;                         // A.width = widest layer output, rounded up to 32
+    float *P = X + HP * ldx;                             // [4][HP][ldh] partial first-layer tiles
+    float *H0 = P + 4 * HP * ldh;                        // [HP][ldh] activations (ping)
+    float *H1 = H0 + HP * ldh;                           // [HP][ldh] activations (pong)
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+    const int fi = lane & 31, fh = lane >> 5;
+    const int p0 = blockIdx.x * HP;
+    const int d = A.d;
+
+    // ---- gather + normalise: wave w owns pairs 8 w .. 8 w + 7 ------------------------------------------------
+    {
+        constexpr int CH = 4;                            // d <= 256: up to 4 elements per lane per row
+        float v[8][2][CH];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pair = p0 + 8 * wid + i;
+            const bool live = pair < A.B;
+            const float *z1 = A.z + (live ? A.ids1[pair] : 0) * A.ldz;
+            const float *z2 = A.z + (live ? A.ids2[pair] : 0) * A.ldz;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int col = lane + WAVE * c;
+                v[i][0][c] = (live && col < d) ? z1[col] : 0.f;
+                v[i][1][c] = (live && col < d) ? z2[col] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) { s1 = fmaf(v[i][0][c], v[i][0][c], s1); s2 = fmaf(v[i][1][c], v[i][1][c], s2); }
+            s1 = group_sum(s1, WAVE);
+            s2 = group_sum(s2, WAVE);
+            const float n1 = fmaxf(sqrtf(s1), A.eps), n2 = fmaxf(sqrtf(s2), A.eps);
+            float *row = X + (8 * wid + i) * ldx;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int col = lane + WAVE * c;
+                if (col < d) { row[col] = v[i][0][c] / n1; row[d + col] = v[i][1][c] / n2; }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- first layer on the matrix cores: wave w multiplies k in [w K0/4, (w+1) K0/4) ---------------------------
+    {
+        const int NT = (N1 + 31) >> 5;
+        float *dst = P + wid * HP * ldh;
+        const float *xa = X + fi * ldx + wid * (K0 >> 2) + fh;
+        if (NT == 1) first_layer_tiles<1>(xa, wfrag_base(A, wid, fh, fi), K0 >> 2, N1, fi, fh, dst, ldh);
+        else if (NT == 2) first_layer_tiles<2>(xa, wfrag_base(A, wid, fh, fi), K0 >> 2, N1, fi, fh, dst, ldh);
+        else first_layer_tiles<4>(xa, wfrag_base(A, wid, fh, fi), K0 >> 2, N1, fi, fh, dst, ldh);
+    }
+    __syncthreads();
+    const bool only = A.num_layers == 1;
+    for (int idx = tid; idx < HP * N1; idx += 256) {     // partial sums (fixed order) + bias + activation
+        const int pr = idx / N1, o = idx - pr * N1;
+        const int off = pr * ldh + o;
+        float s = ((P[off] + P[HP * ldh + off]) + P[2 * HP * ldh + off]) + P[3 * HP * ldh + off];
+        s = apply_act(s + (A.b[0] ? A.b[0][o] : 0.f), only ? A.final_act : A.hidden_act, 0.f);
+        if (only) { if (p0 + pr < A.B) A.out[(int64_t)(p0 + pr) * A.ldo + o] = s; }
+        else H0[off] = s;
+    }
+    // ---- tail layers: one thread per (pair, output) -----------------------------------------------------------
+    float *in = H0, *outb = H1;
+    for (int l = 1; l < A.num_layers; ++l) {
+        __syncthreads();
+        const int K = A.dims[l], N = A.dims[l + 1];
+        const bool last = l == A.num_layers - 1;
+        const float *W = A.w[l];
+        for (int idx = tid; idx < HP * N; idx += 256) {
+            const int pr = idx / N, o = idx - pr * N;
+            float s0 = 0.f, s1 = 0.f;
+            int k = 0;
+            for (; k + 1 < K; k += 2) {
+                s0 = fmaf(in[pr * ldh + k], W[(int64_t)k * N + o], s0);
+                s1 = fmaf(in[pr * ldh + k + 1], W[(int64_t)(k + 1) * N + o], s1);
+            }
+            if (k < K) s0 = fmaf(in[pr * ldh + k], W[(int64_t)k * N + o], s0);
+            const float vv = apply_act(s0 + s1 + (A.b[l] ? A.b[l][o] : 0.f), last ? A.final_act : A.hidden_act, 0.f);
+            if (last) { if (p0 + pr < A.B) A.out[(int64_t)(p0 + pr) * A.ldo + o] = vv; }
+            else outb[pr * ldh + o] = vv;
+        }
+        float *t = in; in = outb; outb = t;
+    }
+}
+
 }  // namespace blgnn
 
 using namespace blgnn;
@@ -160,6 +307,26 @@ extern "C" int blgnn_link_pred_head(const float *z, int64_t ldz, const int64_t *
     A.z = z; A.ldz = ldz; A.ids1 = ids1; A.ids2 = ids2; A.B = B; A.d = d; A.eps = eps;
     A.num_layers = num_layers; A.hidden_act = hidden_act; A.final_act = final_act;
     A.out = out; A.ldo = ldo; A.width = width;
+    // matrix-core variant: first layer <= 512 -> <= 128, every later layer <= 128 wide
+    bool mfma_ok = d <= 256 && dims_host[0] % 8 == 0 && dims_host[0] <= HK_MAX && dims_host[1] <= HN_MAX;
+    for (int l = 2; l <= num_layers; ++l) mfma_ok = mfma_ok && dims_host[l] <= HN_MAX;
+    static const bool force_scalar = getenv("BLGNN_HEAD_SCALAR") != nullptr;      // A/B switch for measurements
+    if (mfma_ok && !force_scalar) {
+        static size_t declared = 0;
+        int wmax = 0;
+        for (int l = 1; l <= num_layers; ++l) wmax = dims_host[l] > wmax ? dims_host[l] : wmax;
+        A.width = (wmax + 31) & ~31;
+        const size_t mbytes = sizeof(float) * ((size_t)HP * (dims_host[0] + 1) + 6 * (size_t)HP * (A.width + 1));
+        if (mbytes > declared && mbytes > 64 * 1024) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_link_head_mfma),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)mbytes) != hipSuccess)
+                return fail(BLGNN_ERR_LAUNCH, "link_pred_head: cannot raise the dynamic LDS limit to %zu bytes", mbytes);
+            declared = mbytes;
+        }
+        hipLaunchKernelGGL(k_link_head_mfma, dim3((unsigned)((B + HP - 1) / HP)), dim3(256), mbytes,
+                           (hipStream_t)stream, A);
+        return launch_status("link_pred_head");
+    }
     size_t wfloats = 0;
     for (int l = 0; l < num_layers; ++l) wfloats += ((size_t)dims_host[l] * dims_host[l + 1] + 3) & ~(size_t)3;
     const size_t act_bytes = sizeof(float) * 4 * 2 * (size_t)width;

@@ -462,7 +462,9 @@ def test_pair_gather_and_normalize(device):
 
 
 @pytest.mark.parametrize("d,dims,final", [(128, [32, 4, 1], "sigmoid"), (64, [16, 2, 3], "identity"),
-                                          (320, [80, 10, 1], "sigmoid"), (50, [7], "identity")])
+                                          (320, [80, 10, 1], "sigmoid"), (50, [7], "identity"),
+                                          (256, [64, 8, 1], "sigmoid"), (96, [24, 3, 1], "sigmoid"),
+                                          (64, [3], "identity"), (200, [100, 50, 3], "identity")])
 def test_link_pred_head_fused(device, d, dims, final):
     g = torch.Generator().manual_seed(d)
     z = torch.randn(300, d, generator=g)
