@@ -60,6 +60,9 @@ def parse():
                     help="how the fused GIN layer runs its dense transforms: fp16 two-piece split (default), "
                          "bf16 three-piece split, or exact-f32 MFMA -- all fp32-equivalent")
     ap.add_argument("--exact-f32", action="store_true", help="same as --transform f32")
+    ap.add_argument("--readout-with-upper", action="store_true",
+                    help="move the node->graph readout from the tail of the molecular sweep's graph to the head of "
+                         "the interaction-level graph (two-stream balance knob; slower at the DrugBank shape)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="replay the lower and upper graphs of a step back to back on one stream")
     ap.add_argument("--no-graph", action="store_true",
@@ -197,7 +200,7 @@ def main():
     from blgnn.engine import BiLevelEngine
     engine = BiLevelEngine(model, lower_batch, upper_batches, graph, sharded=sharded, world_size=world,
                            use_graph=not args.no_graph, overlap=not args.no_overlap,
-                           fuse_lower=args.fuse_lower)
+                           fuse_lower=args.fuse_lower, readout_with_upper=args.readout_with_upper)
     use_graph = engine.use_graph
     engine.capture()
     step = engine.eager_step
@@ -285,6 +288,7 @@ def main():
                        "interaction_pairs": int(len(ds.pair_gids)), "d": D,
                        "pairs_per_step_per_gpu": BATCH_PAIRS, "hip_graph": bool(use_graph),
                        "two_stream_overlap": bool(engine.overlap),
+                       "readout_with_upper": bool(engine.readout_with_upper),
                        "fused_lower_stack": engine.fused is not None,
                        "parallelism": "molecule/pair shards x%d + all-gather(pooled)" % world},
             "roofline": roofline,

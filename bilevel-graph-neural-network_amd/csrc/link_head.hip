@@ -7,7 +7,6 @@
 // as separate GEMM launches it is three grids of mostly idle 32x32 MFMA tiles plus a gather
 // kernel plus two index copies; fused it is one short launch.
 #include "common.hpp"
-#include <stdlib.h>
 
 namespace blgnn {
 
@@ -310,8 +309,7 @@ extern "C" int blgnn_link_pred_head(const float *z, int64_t ldz, const int64_t *
     // matrix-core variant: first layer <= 512 -> <= 128, every later layer <= 128 wide
     bool mfma_ok = d <= 256 && dims_host[0] % 8 == 0 && dims_host[0] <= HK_MAX && dims_host[1] <= HN_MAX;
     for (int l = 2; l <= num_layers; ++l) mfma_ok = mfma_ok && dims_host[l] <= HN_MAX;
-    static const bool force_scalar = getenv("BLGNN_HEAD_SCALAR") != nullptr;      // A/B switch for measurements
-    if (mfma_ok && !force_scalar) {
+    if (mfma_ok) {
         static size_t declared = 0;
         int wmax = 0;
         for (int l = 1; l <= num_layers; ++l) wmax = dims_host[l] > wmax ? dims_host[l] : wmax;

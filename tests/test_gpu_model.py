@@ -195,6 +195,17 @@ def test_engine_graph_replay_and_two_stream_overlap_match_eager(device):
         got = [o.clone() for o in outs[-3:]]
         for k, o in zip(range(4, 7), got):
             assert torch.equal(o, refs[k % 3]), (overlap, k)
+    # per-layer kernels, two streams, with the readout riding in the interaction-level graph (default)
+    # and at the tail of the sweep's graph: the same numbers as the eager per-layer forward
+    for defer in (True, False):
+        eng = BiLevelEngine(model, lower, uppers, g, use_graph=True, overlap=True, fuse_lower=False,
+                            readout_with_upper=defer)
+        assert eng.readout_with_upper == defer
+        eng.capture()
+        outs = [eng.step(i) for i in range(7)]
+        eng.synchronize()
+        for k, o in zip(range(4, 7), [o.clone() for o in outs[-3:]]):
+            assert torch.equal(o, plain[k % 3]), (defer, k)
 
 
 @pytest.mark.parametrize("node_aggr", ["avg_pool", "deepsets", "gmn_aggr"])
