@@ -192,6 +192,27 @@ __global__ void __launch_bounds__(256) k_link_head_mfma(const HeadArgs A) {
     const int p0 = blockIdx.x * HP;
     const int d = A.d;
 
+    // Requests that depend on nothing go first, so their L2 round trips run under the gather's:
+    // this wave's first-layer weight operands (common shape: <= 32 outputs, <= 64 k per wave) and
+    // the tail layers' weights (a few hundred floats) into LDS.
+    const int kq = K0 >> 2;
+    const bool early = N1 <= 32 && kq <= 64;
+    const float *wb = wfrag_base(A, wid, fh, fi);
+    float bpre[32];
+    if (early) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u) bpre[u] = (fi < N1 && 2 * u < kq) ? wb[(int64_t)(2 * u) * N1] : 0.f;
+    }
+    float *TW = H1 + HP * ldh;                           // tail-layer weights, layer after layer (A.w_in_lds)
+    if (A.w_in_lds) {
+        int off = 0;
+        for (int l = 1; l < A.num_layers; ++l) {
+            const int cnt = A.dims[l] * A.dims[l + 1];
+            for (int i = tid; i < cnt; i += 256) TW[off + i] = A.w[l][i];
+            off += cnt;
+        }
+    }
+
     // ---- gather + normalise: wave w owns pairs 8 w .. 8 w + 7 ------------------------------------------------
     {
         constexpr int CH = 4;                            // d <= 256: up to 4 elements per lane per row
@@ -231,10 +252,21 @@ __global__ void __launch_bounds__(256) k_link_head_mfma(const HeadArgs A) {
     {
         const int NT = (N1 + 31) >> 5;
         float *dst = P + wid * HP * ldh;
-        const float *xa = X + fi * ldx + wid * (K0 >> 2) + fh;
-        if (NT == 1) first_layer_tiles<1>(xa, wfrag_base(A, wid, fh, fi), K0 >> 2, N1, fi, fh, dst, ldh);
-        else if (NT == 2) first_layer_tiles<2>(xa, wfrag_base(A, wid, fh, fi), K0 >> 2, N1, fi, fh, dst, ldh);
-        else first_layer_tiles<4>(xa, wfrag_base(A, wid, fh, fi), K0 >> 2, N1, fi, fh, dst, ldh);
+        const float *xa = X + fi * ldx + wid * kq + fh;
+        if (early) {
+            f32x16h acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const float a = 2 * u < kq ? xa[2 * u] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bpre[u], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * fh) * ldh + fi] = acc[r];
+        } else if (NT == 1) first_layer_tiles<1>(xa, wb, kq, N1, fi, fh, dst, ldh);
+        else if (NT == 2) first_layer_tiles<2>(xa, wb, kq, N1, fi, fh, dst, ldh);
+        else first_layer_tiles<4>(xa, wb, kq, N1, fi, fh, dst, ldh);
     }
     __syncthreads();
     const bool only = A.num_layers == 1;
@@ -248,11 +280,13 @@ __global__ void __launch_bounds__(256) k_link_head_mfma(const HeadArgs A) {
     }
     // ---- tail layers: one thread per (pair, output) -----------------------------------------------------------
     float *in = H0, *outb = H1;
+    int tw_off = 0;
     for (int l = 1; l < A.num_layers; ++l) {
         __syncthreads();
         const int K = A.dims[l], N = A.dims[l + 1];
         const bool last = l == A.num_layers - 1;
-        const float *W = A.w[l];
+        const float *W = A.w_in_lds ? TW + tw_off : A.w[l];
+        tw_off += K * N;
         for (int idx = tid; idx < HP * N; idx += 256) {
             const int pr = idx / N, o = idx - pr * N;
             float s0 = 0.f, s1 = 0.f;
@@ -314,7 +348,11 @@ extern "C" int blgnn_link_pred_head(const float *z, int64_t ldz, const int64_t *
         int wmax = 0;
         for (int l = 1; l <= num_layers; ++l) wmax = dims_host[l] > wmax ? dims_host[l] : wmax;
         A.width = (wmax + 31) & ~31;
-        const size_t mbytes = sizeof(float) * ((size_t)HP * (dims_host[0] + 1) + 6 * (size_t)HP * (A.width + 1));
+        size_t tail = 0;
+        for (int l = 1; l < num_layers; ++l) tail += (size_t)dims_host[l] * dims_host[l + 1];
+        A.w_in_lds = tail <= 4096;                       // tail-layer weights staged in LDS (<= 16 KB)
+        const size_t mbytes = sizeof(float) * ((size_t)HP * (dims_host[0] + 1) + 6 * (size_t)HP * (A.width + 1) +
+                                               (A.w_in_lds ? tail : 0));
         if (mbytes > declared && mbytes > 64 * 1024) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_link_head_mfma),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)mbytes) != hipSuccess)
