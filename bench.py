@@ -60,6 +60,11 @@ def parse():
                     help="how the fused GIN layer runs its dense transforms: fp16 two-piece split (default), "
                          "bf16 three-piece split, or exact-f32 MFMA -- all fp32-equivalent")
     ap.add_argument("--exact-f32", action="store_true", help="same as --transform f32")
+    ap.add_argument("--lower-cus", type=int, default=-1,
+                    help="compute units per XCD (of 32) reserved for the molecular sweep's stream; the "
+                         "interaction-level stream gets the rest.  0 = ordinary streams; -1 = the measured optimum "
+                         "for this workload (20 at 1 GPU, 16 at 2, none from 4 GPUs on, where the replicated "
+                         "interaction level wants the whole chip)")
     ap.add_argument("--readout-with-upper", action="store_true",
                     help="move the node->graph readout from the tail of the molecular sweep's graph to the head of "
                          "the interaction-level graph (two-stream balance knob; slower at the DrugBank shape)")
@@ -198,9 +203,12 @@ def main():
     # sweep [+ RCCL all-gather, kept outside capture] of step k+1 overlaps the interaction-level
     # pass + pair scorer of step k.  --no-graph / --no-overlap switch either off.
     from blgnn.engine import BiLevelEngine
+    eff_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
+    lower_cus = {1: 20, 2: 16}.get(eff_world, 0) if args.lower_cus < 0 else args.lower_cus
     engine = BiLevelEngine(model, lower_batch, upper_batches, graph, sharded=sharded, world_size=world,
                            use_graph=not args.no_graph, overlap=not args.no_overlap,
-                           fuse_lower=args.fuse_lower, readout_with_upper=args.readout_with_upper)
+                           fuse_lower=args.fuse_lower, readout_with_upper=args.readout_with_upper,
+                           lower_cus_per_xcd=lower_cus)
     use_graph = engine.use_graph
     engine.capture()
     step = engine.eager_step
@@ -300,6 +308,7 @@ def main():
                        "pairs_per_step_per_gpu": BATCH_PAIRS, "hip_graph": bool(use_graph),
                        "two_stream_overlap": bool(engine.overlap),
                        "readout_with_upper": bool(engine.readout_with_upper),
+                       "lower_cus_per_xcd": engine.lower_cus_per_xcd,
                        "fused_lower_stack": engine.fused is not None,
                        "parallelism": "molecule/pair shards x%d + all-gather(pooled)" % world},
             "roofline": roofline,

@@ -114,7 +114,7 @@ class FusedLowerStack(object):
 
 class BiLevelEngine(object):
     def __init__(self, model, lower_batch, upper_batches, graph, sharded=None, world_size=1,
-                 use_graph=True, overlap=True, fuse_lower=False, readout_with_upper=None):
+                 use_graph=True, overlap=True, fuse_lower=False, readout_with_upper=None, lower_cus_per_xcd=None):
         from .config import FLAGS
         k = FLAGS.last_lower_lyr_num
         self.model = model
@@ -154,6 +154,14 @@ class BiLevelEngine(object):
         self.lower_acts = [None] * self.parities
         self.stream_l = torch.cuda.Stream(device=dev) if self.overlap else None
         self.stream_u = torch.cuda.Stream(device=dev) if self.overlap else None
+        self.lower_cus_per_xcd = None
+        if self.overlap and lower_cus_per_xcd:
+            # each half of the step on its own compute units (blgnn/streams.py)
+            from .streams import cu_partition_streams
+            pair = cu_partition_streams(dev, lower_cus_per_xcd)
+            if pair is not None:
+                self.stream_l, self.stream_u = pair
+                self.lower_cus_per_xcd = int(lower_cus_per_xcd)
         self.ev_lower = [None] * self.parities
         self.ev_upper = [None] * self.parities
         self.step_no = 0

@@ -197,15 +197,18 @@ def test_engine_graph_replay_and_two_stream_overlap_match_eager(device):
             assert torch.equal(o, refs[k % 3]), (overlap, k)
     # per-layer kernels, two streams, with the readout riding in the interaction-level graph (default)
     # and at the tail of the sweep's graph: the same numbers as the eager per-layer forward
-    for defer in (True, False):
+    for defer, cus in ((True, None), (False, None), (False, 20), (True, 12)):
+        # cus: each stream on its own compute units of every XCD (blgnn/streams.py)
         eng = BiLevelEngine(model, lower, uppers, g, use_graph=True, overlap=True, fuse_lower=False,
-                            readout_with_upper=defer)
+                            readout_with_upper=defer, lower_cus_per_xcd=cus)
         assert eng.readout_with_upper == defer
+        if cus and torch.cuda.get_device_properties(device).multi_processor_count == 256:
+            assert eng.lower_cus_per_xcd == cus
         eng.capture()
         outs = [eng.step(i) for i in range(7)]
         eng.synchronize()
         for k, o in zip(range(4, 7), [o.clone() for o in outs[-3:]]):
-            assert torch.equal(o, plain[k % 3]), (defer, k)
+            assert torch.equal(o, plain[k % 3]), (defer, cus, k)
 
 
 @pytest.mark.parametrize("node_aggr", ["avg_pool", "deepsets", "gmn_aggr"])
