@@ -39,10 +39,14 @@ def _masked_stream(device, cu_lo, cu_hi):
 def cu_partition_streams(device, first_cus_per_xcd):
     """-> (stream_a, stream_b): stream_a owns CUs [0, first_cus_per_xcd) of every XCD, stream_b the rest.
     ``first_cus_per_xcd`` is rounded to the hardware's granule of 4 and kept inside [4, 28].  Returns
-    None when the device is not an 8 x 32-CU part (the mask layout above is specific to it)."""
+    None when the device is not an 8 x 32-CU part (the mask layout above is specific to it) or the HIP
+    runtime does not offer masked streams; the caller then keeps ordinary streams."""
     props = torch.cuda.get_device_properties(device)
     if props.multi_processor_count != _XCDS * _CUS_PER_XCD:
         return None
     n = int(round(first_cus_per_xcd / _GRANULE)) * _GRANULE
     n = min(max(n, _GRANULE), _CUS_PER_XCD - _GRANULE)
-    return _masked_stream(device, 0, n), _masked_stream(device, n, _CUS_PER_XCD)
+    try:
+        return _masked_stream(device, 0, n), _masked_stream(device, n, _CUS_PER_XCD)
+    except (OSError, AttributeError, RuntimeError):      # runtime without the extension: ordinary streams
+        return None
