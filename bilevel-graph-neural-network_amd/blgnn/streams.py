@@ -12,6 +12,7 @@ and CUs are granted in groups of four per XCD), and workgroups are dealt round-r
 a partition has to take the same CUs on every XCD or the poorest XCD sets the pace.
 """
 
+import atexit
 import ctypes
 
 import torch
@@ -19,6 +20,25 @@ import torch
 __all__ = ["cu_partition_streams"]
 
 _XCDS, _CUS_PER_XCD, _GRANULE = 8, 32, 4
+_LIVE = []          # (device, raw handle) of every masked stream: destroyed at interpreter exit
+
+
+def _destroy_all():
+    """Masked streams are raw HIP streams torch does not own; leaving them to process teardown
+    crashes tools that finalise after the runtime (rocprofv3 segfaults in __cxa_finalize)."""
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+        torch.cuda.synchronize()
+        while _LIVE:
+            device, handle = _LIVE.pop()
+            with torch.cuda.device(device):
+                hip.hipStreamDestroy(handle)
+    except Exception:                                     # exit path: never raise
+        pass
+
+
+atexit.register(_destroy_all)
 
 
 def _masked_stream(device, cu_lo, cu_hi):
@@ -33,6 +53,7 @@ def _masked_stream(device, cu_lo, cu_hi):
         rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), 8, words)
     if rc != 0 or not handle.value:
         raise RuntimeError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
+    _LIVE.append((device, handle.value))
     return torch.cuda.ExternalStream(handle.value, device=device)
 
 

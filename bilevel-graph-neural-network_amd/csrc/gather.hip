@@ -456,20 +456,20 @@ static void launch_spmm_tile(const GatherArgs &A, hipStream_t s) {
 // Partial rows meet by wave shuffles, then in LDS ([4][d]) in a fixed order (deterministic).
 // A kernel that gives each row to ONE lane group runs as long as its heaviest row: 241 us vs
 // ~20 us for the upper GAT of the DrugBank-shape graph.
+constexpr int WIDE_EDGES = 256;
 
-template <int MODE, int LG, int CH, int NW>
-__global__ void __launch_bounds__(64 * NW) k_gather_wide(const GatherArgs A) {
+template <int MODE, int LG, int CH>
+__global__ void __launch_bounds__(256) k_gather_wide(const GatherArgs A) {
     constexpr int S = WAVE / LG;                 // edge slots per wave
-    constexpr int NSLOT = NW * S;                // NW wavefronts per row
-    constexpr int NE = 64 * NW;                  // edges parked per pass (one per thread)
+    constexpr int NSLOT = 4 * S;
     constexpr int U = CH <= 1 ? 8 : (CH <= 2 ? 4 : 2);   // neighbour rows in flight per slot
-    extern __shared__ float4 part4[];            // [NW][d4] float4, then the parked edges
+    extern __shared__ float4 part4[];            // [4][d4] float4, then the parked edges
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
     const int sub = lane / LG, l = lane % LG;
     const int slot = wid * S + sub;
     const int d4 = A.d >> 2;
-    int *js = reinterpret_cast<int *>(part4 + NW * d4);
-    float *ws = reinterpret_cast<float *>(js + NE);
+    int *js = reinterpret_cast<int *>(part4 + 4 * d4);
+    float *ws = reinterpret_cast<float *>(js + WIDE_EDGES);
     const float4 *__restrict__ X = reinterpret_cast<const float4 *>(A.x);
     const int64_t ldx4 = A.ldx >> 2, ldy4 = A.ldy >> 2, ldp4 = A.ldp >> 2;
 
@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(64 * NW) k_gather_wide(const GatherArgs A) {
             }
         }
         const int e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
-        for (int base = e0; base < e1; base += NE) {
+        for (int base = e0; base < e1; base += WIDE_EDGES) {
             {   // (a) one edge per thread
                 const int ee = base + threadIdx.x;
                 int j = row;
@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(64 * NW) k_gather_wide(const GatherArgs A) {
                 ws[threadIdx.x] = w;
             }
             __syncthreads();
-            const int cnt = (e1 - base) < NE ? (e1 - base) : NE;
+            const int cnt = (e1 - base) < WIDE_EDGES ? (e1 - base) : WIDE_EDGES;
             for (int t = slot; t < cnt; t += U * NSLOT) {
                 int j[U];
                 float w[U];
@@ -566,13 +566,9 @@ __global__ void __launch_bounds__(64 * NW) k_gather_wide(const GatherArgs A) {
         __syncthreads();
         float4 *Y = reinterpret_cast<float4 *>(A.y) + (int64_t)row * ldy4;
         for (int c4 = threadIdx.x; c4 < d4; c4 += blockDim.x) {
-            float4 a = part4[c4], b = part4[d4 + c4];
-            float t[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
-            if (NW == 4) {
-                const float4 c = part4[2 * d4 + c4], dd = part4[3 * d4 + c4];
-                t[0] = (a.x + b.x) + (c.x + dd.x); t[1] = (a.y + b.y) + (c.y + dd.y);
-                t[2] = (a.z + b.z) + (c.z + dd.z); t[3] = (a.w + b.w) + (c.w + dd.w);
-            }
+            float4 a = part4[c4], b = part4[d4 + c4], c = part4[2 * d4 + c4], dd = part4[3 * d4 + c4];
+            float t[4] = {(a.x + b.x) + (c.x + dd.x), (a.y + b.y) + (c.y + dd.y),
+                          (a.z + b.z) + (c.z + dd.z), (a.w + b.w) + (c.w + dd.w)};
             if (MODE == MODE_GCN || MODE == MODE_GAT) {
                 const float4 o = A.accumulate ? Y[c4] : f4_zero();
                 const float oo[4] = {o.x, o.y, o.z, o.w};
@@ -646,15 +642,8 @@ static void launch_vec(const GatherArgs &A, hipStream_t s) {
 template <int MODE, int LG, int CH>
 static void launch_wide(const GatherArgs &A, hipStream_t s) {
     const int blocks = A.n < 256 * 32 ? A.n : 256 * 32;
-    // a row is a chain of dependent round trips (rowptr -> col -> per-edge scalars -> rows), so a few
-    // thousand rows (the interaction level of one GPU) run fastest when every row has its workgroup
-    // resident at once: two wavefronts per row, twice the workgroups per CU.  Larger graphs keep four.
-    if (A.n <= 4096)
-        hipLaunchKernelGGL((k_gather_wide<MODE, LG, CH, 2>), dim3(blocks), dim3(128),
-                           (size_t)A.d * 8 + 128 * 8, s, A);
-    else
-        hipLaunchKernelGGL((k_gather_wide<MODE, LG, CH, 4>), dim3(blocks), dim3(256),
-                           (size_t)A.d * 16 + 256 * 8, s, A);
+    hipLaunchKernelGGL((k_gather_wide<MODE, LG, CH>), dim3(blocks), dim3(256),
+                       (size_t)A.d * 16 + WIDE_EDGES * 8, s, A);
 }
 
 // rows this heavy on average go one-workgroup-per-row (see k_gather_wide)

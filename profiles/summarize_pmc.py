@@ -28,5 +28,7 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     res["hbm_bytes_per_launch"] = res["hbm_read_bytes_per_launch"] + res["hbm_write_bytes_per_launch"]
     res["correction"] = "FETCH_SIZE x2 (gfx950 wide-read undercount), WRITE_SIZE x1, both x1024 (KB)"
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), tag + "_pmc_summary.json")
+if not c:
+    sys.exit("no counter rows for kernel %r under %s: summary left as it is" % (sub, sys.argv[3:]))
 json.dump(res, open(path, "w"), indent=1)
 print(json.dumps(res))
