@@ -65,6 +65,23 @@ def test_bignn_forward(device, lower, upper, d):
         assert max_err(got, ref) < TOL
 
 
+@pytest.mark.parametrize("transform", ["f16x3", "bf16x6", "f32"])
+def test_bignn_forward_under_each_feature_transform(device, transform):
+    """the three ways the fused GIN layer runs its dense transforms (fp16 two-piece split, bf16 three-piece
+    split, exact-f32 MFMA) all meet the same 1e-5 bar on the whole bi-level forward at d=128"""
+    ds = blgnn.make_synthetic(90, 500, seed=4, device=device)
+    flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin",
+                             higher_level_gnn_type="gat", D_lower=128, D_higher=128, device=device,
+                             feature_transform=transform)
+    model, data = build(flags, ds, seed=9)
+    specs = layer_specs(flags)
+    pairs = _pairs(ds, 48)
+    init_ref, acts_ref = _oracle_bilevel(model, flags, ds, specs, pairs)
+    preds, bd = bilevel_forward(model, data, pairs)
+    assert max_err(ds.interaction_combo_nxgraph.init_x, init_ref) < TOL
+    assert max_err(preds, acts_ref[-1]) < TOL
+
+
 @pytest.mark.parametrize("group", ["src", "dst"])
 def test_decagon_forward(device, group):
     ds = blgnn.make_synthetic(80, 600, seed=2, device=device)
