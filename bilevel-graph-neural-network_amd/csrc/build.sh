@@ -10,7 +10,10 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function"
 pids=()
 for f in runtime graph_layout gather readout linear linear_x6 gat_transform gmn_match gin_fused gin_x6 gin_h3 gin_stack link_head; do
   src="$here/$f.hip"; obj="$here/obj/$f.o"
-  if [[ ! -f "$obj" || "$src" -nt "$obj" || "$here/common.hpp" -nt "$obj" || "$here/gin_common.hpp" -nt "$obj" || "$here/../../include/blgnn.h" -nt "$obj" ]]; then
+  stale=0
+  [[ -f "$obj" && "$src" -ot "$obj" ]] || stale=1
+  for h in "$here"/*.hpp "$here/../../include/blgnn.h"; do [[ "$h" -nt "$obj" ]] && stale=1; done
+  if [[ $stale -eq 1 ]]; then
     $HIPCC $FLAGS -c "$src" -o "$obj" &
     pids+=($!)
   fi
