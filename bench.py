@@ -1,27 +1,38 @@
 #!/usr/bin/env python3
 """Headline benchmark: DDI edge-pairs/sec of the bi-level forward on N MI355X.
 
-Workload (BASELINE.json configs[1]): DrugBank-shaped synthetic data -- 1 326 drugs per GPU
-(log-normal molecule sizes, ~28 atoms, F_in = 52), interaction graph with 29 240 train pairs
-per 1 326 drugs, lower GIN x5 (d=128) + multi-scale avg-pool readout + upper GAT x3 +
-LinkPred; 4 096 edge pairs scored per GPU per step.
+``--config`` selects one of BASELINE.json's five configs (0-based); the default is configs[2], the
+largest single-GPU configuration:
 
-One step = one complete bi-level forward (src/train.py:75-108 of the reference):
-  lower sweep over this rank's molecules -> readout -> [all-gather of pooled drug
-  embeddings over RCCL when N > 1] -> interaction-level GAT x3 -> pair scores for this
-  rank's 4 096 pairs.  Inputs (features, edge lists, pair ids) are resident in HBM before
-  the timed region; the molecule set and the interaction graph are static, so their CSR
-  layouts are built once (the reference rebuilds both per forward).
+  0  DrugBank shape, lower GIN x5 + upper GAT x3, d=64,  32 pairs per GPU per step        (weak)
+  1  DrugBank shape, lower GIN x5 + upper GAT x3, d=128, 4 096 pairs per GPU per step     (weak)
+  2  DrugCombo shape, multi-label head, lower GIN + GMN cross-graph attention x3, d=256,
+     8 192 pairs per GPU per step in pair mode (16 384 molecule instances, ~480 k atoms)   (weak)
+  3  100 k drugs x ~40 atoms, lower GIN x5 (d=256, multi-scale readout 1 280) sharded over the ranks
+     -> all-gather of the pooled rows -> upper GAT x3 on 1 M interaction pairs; 65 536 pairs scored
+     per step, split over the ranks                                                         (strong)
+  4  d=512, GMN on, pairs drawn from 1 M interaction edges, 8 192 pairs per step split over
+     the ranks                                                                              (strong)
 
-Weak scaling: per-GPU work is fixed; value = N * 4096 * steps / max-over-ranks time.
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the
-dominant kernel (fp32-MFMA feature transform of the lower level, timed live with HIP events
-on the launch stream) and `cpu_baseline` (the CPU oracle on the host cores, bounded sample).
+One step = one complete forward of the reference's evaluation path (src/train.py:75-108,185-220) on
+one batch of edge pairs.  Bi-level configs: lower sweep over this rank's molecules -> readout ->
+[all-gather of pooled drug embeddings over RCCL when N > 1] -> interaction-level conv x3 -> pair
+scores; every step scores a FRESH random batch (one 16-byte-per-pair H2D id copy per step, inside the
+timed region).  GMN configs: NodeEmbedding / GMNPropagator x3 over the merged pair batch -> readout
+-> pair scores, cycling through pre-built batches resident in HBM.
+
+``--gpus N`` without a torchrun environment starts the N ranks itself (child processes, RCCL).
+Timing: W warm-up steps, then blocks of EXACTLY K steps bracketed by barrier + synchronize, MAX over
+ranks; blocks repeat until >= 0.5 s has been timed and the MEDIAN block is reported.
+Prints ONE JSON line on rank 0 with `roofline` for the config's dominant kernel (HIP events on the
+launch stream) and `cpu_baseline` (the CPU oracle on the host cores, bounded sample).
 """
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,59 +41,120 @@ for _p in (ROOT, os.path.join(ROOT, "bilevel-graph-neural-network_amd"), os.path
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
-DRUGS_PER_GPU = 1326
-PAIRS_PER_DRUGSET = 29240      # 70 % train split of DrugBank's 41 772 pairs
-BATCH_PAIRS = 4096
-D = 128
-SEED = 20200614 + 2
+SEED = 20200614
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA (same table)
+PEAK_16BIT_MFMA_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA (same table)
 PEAK_HBM_GBPS = 8000.0
+MIN_TIMED_SECONDS = 0.5
+
+CONFIGS = {
+    0: dict(kind="bilevel", shape="drugbank", drugs=1326, pairs=29240, d=64, batch=32, scaling="weak",
+            name="DrugBank-shape DDI, lower GIN x5 + upper GAT x3, d=64, batch=32 edge pairs per GPU "
+                 "(BASELINE configs[0])"),
+    1: dict(kind="bilevel", shape="drugbank", drugs=1326, pairs=29240, d=128, batch=4096, scaling="weak",
+            name="DrugBank-shape DDI, lower GIN x5 + upper GAT x3, d=128, batch=4096 edge pairs per GPU "
+                 "(BASELINE configs[1])"),
+    2: dict(kind="gmn", shape="drugcombo", drugs=3376, pairs=50263, d=256, batch=8192, scaling="weak",
+            dataset="drugcombo", edge_types=2,
+            name="DrugCombo-shape multi-label DDI, lower GIN + GMN cross-graph attention x3, d=256, "
+                 "batch=8192 edge pairs per GPU, pair mode (BASELINE configs[2])"),
+    3: dict(kind="bilevel", shape="atoms40", drugs=100000, pairs=1000000, d=256, batch=65536, scaling="strong",
+            name="synthetic bi-level: 100k drugs x ~40 atoms, lower GIN x5 d=256 sharded + all-gather + upper "
+                 "GAT x3 on 1M pairs, 65536 edge pairs per step over all GPUs (BASELINE configs[3])"),
+    4: dict(kind="gmn", shape="atoms40", drugs=100000, pairs=1000000, d=512, batch=8192, scaling="strong",
+            dataset="drugbank", edge_types=1,
+            name="synthetic 1M interaction edges, lower GIN + GMN x3, d=512, 8192 edge pairs per step over all "
+                 "GPUs, pair mode (BASELINE configs[4])"),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+                    help="index into BASELINE.json configs (default 2: DrugCombo d=256 B=8192 GMN)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the d=256 SpMM/readout micro-roofline")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the extras: configs[1] summary and the d=256 SpMM/readout micro-roofline")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="profiling aid: build rank 0's share of an N-GPU run on one GPU (no collective)")
     ap.add_argument("--fuse-lower", action="store_true",
                     help="run the lower level as ONE launch (blgnn_gin_stack) instead of one per GIN layer")
     ap.add_argument("--transform", choices=("f16x3", "bf16x6", "f32"), default="f16x3",
-                    help="how the fused GIN layer runs its dense transforms: fp16 two-piece split (default), "
-                         "bf16 three-piece split, or exact-f32 MFMA -- all fp32-equivalent")
+                    help="how the dense transforms run: fp16 two-piece split (default), bf16 three-piece split, "
+                         "or exact-f32 MFMA -- all fp32-equivalent")
     ap.add_argument("--exact-f32", action="store_true", help="same as --transform f32")
     ap.add_argument("--lower-cus", type=int, default=-1,
-                    help="compute units per XCD (of 32) reserved for the molecular sweep's stream; the "
-                         "interaction-level stream gets the rest.  0 = ordinary streams; -1 = the measured optimum "
-                         "for this workload (20 at 1 GPU, 16 at 2, none from 4 GPUs on, where the replicated "
-                         "interaction level wants the whole chip)")
-    ap.add_argument("--readout-with-upper", action="store_true",
-                    help="move the node->graph readout from the tail of the molecular sweep's graph to the head of "
-                         "the interaction-level graph (two-stream balance knob; slower at the DrugBank shape)")
+                    help="bi-level configs: compute units per XCD (of 32) reserved for the molecular sweep's stream; "
+                         "the interaction-level stream gets the rest.  0 = ordinary streams; -1 = the measured "
+                         "optimum (20 at 1 GPU, 16 at 2, none from 4 GPUs on / for the large configs)")
+    ap.add_argument("--readout-with-upper", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="replay the lower and upper graphs of a step back to back on one stream")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel eagerly instead of replaying captured HIP graphs")
+    ap.add_argument("--min-seconds", type=float, default=MIN_TIMED_SECONDS)
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------
+# --gpus N without a launcher: start the N ranks here, before anything touches the GPU
+# ---------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """Spawn ``args.gpus`` child processes of this script (one per GPU, RCCL rendezvous on 127.0.0.1),
+    pass rank 0's stdout through and exit non-zero if any rank fails.  The parent never initialises
+    the GPU (and never re-execs)."""
+    n = args.gpus
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "BLGNN_BENCH_CHILD": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = None if r == 0 else subprocess.DEVNULL          # rank 0 prints the one JSON line
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    rcs = [None] * n
+    deadline = time.time() + 3300
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        failed = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
+        if failed or time.time() > deadline:
+            for p in procs:                                   # exact PIDs we started
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            why = "rank(s) %s exited non-zero" % failed if failed else "timed out"
+            raise SystemExit("bench.py --gpus %d: %s (%s): no result line is valid" % (n, why, rcs))
+        time.sleep(0.2)
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# timing helpers
+# ---------------------------------------------------------------------------------------------------
 class KernelTimer(object):
     """HIP-event timing of one op's launches on the stream they are launched on
     (torch's current stream == the stream handed to libblgnn)."""
 
     def __init__(self):
-        self.pairs, self.work, self.enabled = [], [], False
+        self.pairs, self.work, self.names, self.enabled = [], [], [], False
 
-    def wrap(self, fn, work_of, select):
+    def wrap(self, name, fn, work_of, select):
+        import torch
+
         def wrapped(*a, **k):
             if not self.enabled or not select(*a, **k):
                 return fn(*a, **k)
@@ -93,243 +165,500 @@ class KernelTimer(object):
             e1.record()
             self.pairs.append((e0, e1))
             self.work.append(work_of(*a, **k))
+            self.names.append(name)
             return out
         return wrapped
 
     def result(self):
         ms = [a.elapsed_time(b) for a, b in self.pairs]
-        return ms, self.work
+        return ms, self.work, self.names
 
 
-def build_workload(rank, world, device, transform="f16x3"):
-    import blgnn
-    from blgnn.dist import ShardedLower
-    n_drugs = DRUGS_PER_GPU * world
-    ds = blgnn.make_synthetic(n_drugs, PAIRS_PER_DRUGSET * world, shape="drugbank", seed=SEED, device=device)
-    flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin",
-                             higher_level_gnn_type="gat", D_lower=D, D_higher=D, device=device,
-                             batch_size=BATCH_PAIRS, feature_transform=transform)
-    blgnn.set_flags(flags)
-    torch.manual_seed(SEED)
-    data = blgnn.TrainData(ds, device=device)
-    ds.init_interaction_graph_feats(flags.init_embds, device, flags.d_init)
-    model = blgnn.Model(data)
-    g = torch.Generator().manual_seed(SEED + 1)
-    with torch.no_grad():                      # eval BN, running stats perturbed by U(-0.1, 0.1)
+def timed_blocks(run_block, min_seconds, max_blocks=200):
+    """run_block() -> seconds for exactly K steps (barrier + synchronize on both sides, MAX over ranks, so
+    every rank sees the same number and takes the same decision).  Repeats until ``min_seconds`` have been
+    timed; returns (median, all block times)."""
+    times = []
+    while True:
+        times.append(run_block())
+        if sum(times) >= min_seconds or len(times) >= max_blocks:
+            break
+    s = sorted(times)
+    return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2]), times
+
+
+def usable_cores():
+    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota
+    (a 1-GPU box exposes all 256 hardware threads but grants a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def perturb_bn(model, seed):
+    """eval BN, running stats perturbed by U(-0.1, 0.1)"""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
         for mod in model.modules():
             if isinstance(mod, torch.nn.BatchNorm1d):
                 mod.running_mean.copy_(0.2 * (torch.rand(mod.running_mean.shape, generator=g) - 0.5))
                 mod.running_var.copy_(1.0 + 0.2 * (torch.rand(mod.running_var.shape, generator=g) - 0.5))
-    model.to(device).eval()
-    sharded = ShardedLower(ds.molecules.gids, ds.molecules.sizes, rank, world)
-    return ds, flags, data, model, sharded
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; the hot path has no CPU fallback")
-    # BLGNN_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks
-    backend = os.environ.get("BLGNN_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    device = "cuda:%d" % dev_index
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+def pmc_traffic(tag):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/summarize_pmc.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction), or None."""
+    for rnd in ("r02", "r01"):
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.json" % (rnd, tag))))[
+                "hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
+
+def roofline_of(kname, ms, work, mfma_mult, mfma_peak, traffic):
+    """Two floors per launch -- algorithmic bytes at the HBM peak and EXECUTED matrix-core flops (3x / 6x /
+    1x the algorithmic fp32 flops for f16x3 / bf16x6 / f32) at the dense peak of the MFMA dtype; the higher
+    one is the binding roofline and is what `frac` is quoted against."""
+    tot = sum(ms) * 1e-3
+    flops, byts = sum(w[0] for w in work), sum(w[1] for w in work)
+    tflops = flops / tot / 1e12 if tot else 0.0
+    gbps = byts / tot / 1e9 if tot else 0.0
+    exec_tflops = mfma_mult * tflops
+    mfma_frac, hbm_frac = exec_tflops / mfma_peak, gbps / PEAK_HBM_GBPS
+    by_hbm = hbm_frac >= mfma_frac
+    n = max(len(ms), 1)
+    return {"kernel": kname, "bound": "hbm" if by_hbm else "mfma",
+            "achieved": gbps if by_hbm else exec_tflops,
+            "peak": PEAK_HBM_GBPS if by_hbm else mfma_peak,
+            "unit": "GB/s" if by_hbm else "TFLOP/s",
+            "frac": hbm_frac if by_hbm else mfma_frac, "traffic": traffic,
+            "alg_bytes_per_launch": byts / n, "alg_flops_per_launch": flops / n,
+            "launches": len(ms), "avg_us": 1e3 * sum(ms) / n,
+            "alg_hbm_GBps": gbps, "alg_hbm_frac": hbm_frac,
+            "executed_mfma_tflops": exec_tflops, "executed_mfma_frac": mfma_frac, "mfma_peak_tflops": mfma_peak,
+            "algorithmic_f32_tflops": tflops, "frac_of_f32_mfma_peak": tflops / PEAK_F32_MFMA_TFLOPS}
+
+
+MFMA_OF = {"f16x3": (3.0, PEAK_16BIT_MFMA_TFLOPS), "bf16x6": (6.0, PEAK_16BIT_MFMA_TFLOPS), "f32": (1.0, PEAK_F32_MFMA_TFLOPS)}
+DTYPE_OF = {"f16x3": "f32 (dense transforms as f16x3 split MFMA, fp32-equivalent)",
+            "bf16x6": "f32 (dense transforms as bf16x6 split MFMA, fp32-equivalent)", "f32": "f32"}
+
+
+class Dist(object):
+    """The process group as the bench needs it: barrier, MAX of a float, world/rank."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X; the hot path has no CPU fallback")
+        # BLGNN_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks
+        self.backend = os.environ.get("BLGNN_BENCH_BACKEND", "nccl")
+        ndev = torch.cuda.device_count()
+        if self.backend == "nccl" and self.world > ndev:
+            raise SystemExit("--gpus %d but only %d device(s) visible" % (self.world, ndev))
+        dev_index = local_rank % ndev
+        torch.cuda.set_device(dev_index)
+        self.device = "cuda:%d" % dev_index
+        self.dist = dist
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                        device_id=torch.device(self.device))
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+            joined = torch.ones(1, device=self.device if self.backend == "nccl" else "cpu")
+            dist.all_reduce(joined)
+            if int(joined.item()) != self.world:
+                raise SystemExit("only %d of %d ranks joined" % (int(joined.item()), self.world))
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max(self, v):
+        import torch
+        if self.world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=self.device if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def block_runner(D, step_fn, sync_fn, steps):
+    """-> run_block(): seconds for exactly ``steps`` steps, barrier + synchronize on both sides, MAX over ranks."""
+    import torch
+    counter = [0]
+
+    def run_block():
+        sync_fn()
+        torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn(counter[0])
+            counter[0] += 1
+        sync_fn()
+        D.barrier()
+        torch.cuda.synchronize()
+        return D.max(time.perf_counter() - t0)
+    return run_block, counter
+
+
+# ---------------------------------------------------------------------------------------------------
+# bi-level configs (0, 1, 3): molecular sweep -> [all-gather] -> interaction level -> pair scores
+# ---------------------------------------------------------------------------------------------------
+def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roofline=True):
+    import numpy as np
+    import torch
     import blgnn
     from blgnn import ops
     from blgnn.batch import BatchData
+    from blgnn.dist import ShardedLower
+    from blgnn.engine import BiLevelEngine
     from blgnn.forward import all_molecule_pairs
-
-    transform = "f32" if args.exact_f32 else args.transform
-    if args.emulate_world > 1 and world == 1:
-        ds, flags, data, model, sharded = build_workload(0, args.emulate_world, device, transform)
+    cfg = CONFIGS[cfg_id]
+    world, rank, device = D.world, D.rank, D.device
+    emu = args.emulate_world if (args.emulate_world > 1 and world == 1) else 0
+    eff_world = emu or world
+    weak = cfg["scaling"] == "weak"
+    d = cfg["d"]
+    n_drugs = cfg["drugs"] * (eff_world if weak else 1)
+    n_pairs = cfg["pairs"] * (eff_world if weak else 1)
+    batch = cfg["batch"] if weak else cfg["batch"] // eff_world
+    seed = SEED + cfg_id + 1
+    ds = blgnn.make_synthetic(n_drugs, n_pairs, shape=cfg["shape"], seed=seed, device=device)
+    flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin",
+                             higher_level_gnn_type="gat", D_lower=d, D_higher=d, device=device,
+                             batch_size=batch, feature_transform=transform)
+    blgnn.set_flags(flags)
+    torch.manual_seed(seed)
+    data = blgnn.TrainData(ds, device=device)
+    ds.init_interaction_graph_feats(flags.init_embds, device, flags.d_init)
+    model = blgnn.Model(data)
+    perturb_bn(model, seed + 1)
+    model.to(device).eval()
+    sharded = ShardedLower(ds.molecules.gids, ds.molecules.sizes, 0 if emu else rank, eff_world)
+    if emu:
+        sharded_engine, engine_world = None, 1
     else:
-        ds, flags, data, model, sharded = build_workload(rank, world, device, transform)
-    k = flags.last_lower_lyr_num
-    lower_layers = list(model.layers[:k + 1])
-    upper_layers = list(model.layers[k + 1:-1])          # LoadInteraction, GAT x3, LinkPred (no Loss)
+        sharded_engine, engine_world = sharded, world
 
     # -- static inputs, resident in HBM before timing -------------------------------------
     lower_batch = BatchData(all_molecule_pairs(sharded.local_gids), ds, is_train=False, ignore_pairs=True)
     lower_batch.merge_data['merge'].csr()
     graph = ds.interaction_combo_nxgraph
-    d_pool = D * 5
-    graph.init_x = torch.zeros((ds.num_graphs(), d_pool), dtype=torch.float32, device=device)
+    graph.init_x = torch.zeros((ds.num_graphs(), d * 5), dtype=torch.float32, device=device)
     ds.init = True
-    rng = np.random.default_rng(SEED + 17 + rank)
-    n_batches = 8
-    upper_batches = []
-    for _ in range(n_batches):
-        idx = rng.choice(len(ds.pair_gids), size=BATCH_PAIRS, replace=False)
-        b = BatchData(ds.pair_gids[idx], ds, is_train=False)
-        upper_batches.append(b)
+    rng = np.random.default_rng(seed + 17 + rank)
+    template = BatchData(ds.pair_gids[rng.choice(len(ds.pair_gids), size=batch, replace=False)], ds, is_train=False)
     Nn = int(lower_batch.merge_data['merge'].x.shape[0])
     nnz = int(lower_batch.merge_data['merge'].edge_index.shape[1])
 
-    # dominant kernel: the fused GIN layer (CSR gather -> LDS -> 2 matrix-core GEMMs -> epilogue),
-    # bf16x6 variant by default (FLAGS.feature_transform), exact-f32 MFMA variant otherwise
+    # dominant kernel: the fused GIN layer (CSR gather -> LDS -> 2 matrix-core GEMMs -> epilogue)
     timer = KernelTimer()
-    real_gin, real_gin6, real_gin3 = ops.gin_layer, ops.gin_layer_x6, ops.gin_layer_h3
-    ops.gin_layer = timer.wrap(
-        real_gin,
-        lambda csr, x, w1, b1, w2, *a, **kw: (2.0 * x.shape[0] * (w1.shape[0] * w1.shape[1] + w2.shape[0] * w2.shape[1]),
-                                              4.0 * x.shape[0] * (x.shape[1] + w1.shape[1]) + 4.0 * csr.nnz + 4.0 * (csr.n + 1)),
-        lambda *a, **kw: True)
-    ops.gin_layer_x6 = timer.wrap(
-        real_gin6,
-        lambda csr, x, w1p, b1, w2p, b2, N, *a, **kw: (2.0 * x.shape[0] * (x.shape[1] * N + N * N),
-                                                       4.0 * x.shape[0] * (x.shape[1] + N) + 4.0 * csr.nnz + 4.0 * (csr.n + 1)),
-        lambda *a, **kw: True)
-    ops.gin_layer_h3 = timer.wrap(
-        real_gin3,
-        lambda csr, x, w1p, b1, w2p, b2, N, *a, **kw: (2.0 * x.shape[0] * (x.shape[1] * N + N * N),
-                                                       4.0 * x.shape[0] * (x.shape[1] + N) + 4.0 * csr.nnz + 4.0 * (csr.n + 1)),
-        lambda *a, **kw: True)
-    mode = getattr(flags, "feature_transform", "f16x3")
+    saved = (ops.gin_layer, ops.gin_layer_x6, ops.gin_layer_h3)
+    work_f32 = lambda csr, x, w1, b1, w2, *a, **kw: (
+        2.0 * x.shape[0] * (w1.shape[0] * w1.shape[1] + w2.shape[0] * w2.shape[1]),
+        4.0 * x.shape[0] * (x.shape[1] + w1.shape[1]) + 4.0 * csr.nnz + 4.0 * (csr.n + 1))
+    work_split = lambda csr, x, w1p, b1, w2p, b2, N, *a, **kw: (
+        2.0 * x.shape[0] * (x.shape[1] * N + N * N),
+        4.0 * x.shape[0] * (x.shape[1] + N) + 4.0 * csr.nnz + 4.0 * (csr.n + 1))
+    ops.gin_layer = timer.wrap("f32", saved[0], work_f32, lambda *a, **kw: True)
+    ops.gin_layer_x6 = timer.wrap("bf16x6", saved[1], work_split, lambda *a, **kw: True)
+    ops.gin_layer_h3 = timer.wrap("f16x3", saved[2], work_split, lambda *a, **kw: True)
 
-    # The forward is ~35 short launches: captured into HIP graphs and replayed, and consecutive
-    # forwards are software-pipelined over two HIP streams (blgnn/engine.py): the molecular
-    # sweep [+ RCCL all-gather, kept outside capture] of step k+1 overlaps the interaction-level
-    # pass + pair scorer of step k.  --no-graph / --no-overlap switch either off.
-    from blgnn.engine import BiLevelEngine
-    eff_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
-    lower_cus = {1: 20, 2: 16}.get(eff_world, 0) if args.lower_cus < 0 else args.lower_cus
-    engine = BiLevelEngine(model, lower_batch, upper_batches, graph, sharded=sharded, world_size=world,
+    big = cfg["drugs"] > 10000
+    lower_cus = ({1: 20, 2: 16}.get(eff_world, 0) if not big else 0) if args.lower_cus < 0 else args.lower_cus
+    engine = BiLevelEngine(model, lower_batch, template, graph, sharded=sharded_engine, world_size=engine_world,
                            use_graph=not args.no_graph, overlap=not args.no_overlap,
                            fuse_lower=args.fuse_lower, readout_with_upper=args.readout_with_upper,
                            lower_cus_per_xcd=lower_cus)
-    use_graph = engine.use_graph
-    engine.capture()
-    step = engine.eager_step
-    run = engine.step
-    for i in range(args.warmup):
-        run(i)
-    engine.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    timer.enabled = not use_graph
-    for i in range(args.steps):
-        preds = run(i)
-    engine.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    timer.enabled = False
-    if use_graph:
-        # HIP events cannot sit inside a replayed graph: the dominant kernel is timed over the
-        # same K steps launched eagerly right after the timed region (same inputs, same stream)
-        # A long matmul is queued ahead of every step so that the step's launches wait in the
-        # queue and the events bracket back-to-back execution, not host launch latency.
-        timer.enabled = True
-        blk = torch.empty(4096, 8192, device=device)
-        blk_w = torch.empty(8192, 8192, device=device)
-        for i in range(args.steps):
-            torch.mm(blk, blk_w)
-            step(i)
-        torch.cuda.synchronize()
-        timer.enabled = False
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert preds.shape == (BATCH_PAIRS, 1) and bool(torch.isfinite(preds).all())
+    try:
+        engine.capture()
+        # a fresh random batch of pair ids every step (src/sampler.py:120-131), drawn ahead of the timed
+        # region; the engine maps gid -> row and copies the 16 B/pair to the device inside the step
+        pool = max(64, steps + warmup)
+        fresh = [ds.pair_gids[rng.choice(len(ds.pair_gids), size=batch, replace=False)] for _ in range(pool)]
+        last = [None]
 
-    ms, work = timer.result()
-    ops.gin_layer, ops.gin_layer_x6, ops.gin_layer_h3 = real_gin, real_gin6, real_gin3
-    out = None
-    if rank == 0:
-        value = world * BATCH_PAIRS * args.steps / elapsed
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-        # (profiles/summarize_pmc.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction)
-        traffic = None
-        try:
-            name = {"f16x3": "r01_gin_layer_h3_pmc_summary.json", "bf16x6": "r01_gin_layer_x6_pmc_summary.json",
-                    "f32": "r01_gin_layer_pmc_summary.json"}[mode]
-            traffic = json.load(open(os.path.join(ROOT, "profiles", name)))["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
-        tflops = sum(w[0] for w in work) / (sum(ms) * 1e-3) / 1e12 if ms else 0.0
-        alg_gbps = sum(w[1] for w in work) / (sum(ms) * 1e-3) / 1e9 if ms else 0.0
-        # split transforms: every algorithmic fp32 product is three fp16 (f16x3) or six bf16 (bf16x6) MFMA
-        # products -> the executed matrix-core rate is 3x / 6x the algorithmic one and is priced against the
-        # dense fp16 / bf16 peak (the same 2.5 PFLOP/s)
-        mfma_mult, peak = {"f16x3": (3.0, PEAK_BF16_MFMA_TFLOPS), "bf16x6": (6.0, PEAK_BF16_MFMA_TFLOPS),
-                           "f32": (1.0, PEAK_F32_MFMA_TFLOPS)}[mode]
+        def one(i):
+            last[0] = engine.step(fresh[i % pool])
+        for i in range(warmup):
+            one(i)
+        run_block, counter = block_runner(D, one, engine.synchronize, steps)
+        counter[0] = warmup
+        elapsed, blocks = timed_blocks(run_block, min_seconds)
+        preds = last[0]
+        assert preds.shape == (batch, 1) and bool(torch.isfinite(preds).all())
+
+        # HIP events cannot sit inside a replayed graph: the dominant kernel is timed over K steps launched
+        # eagerly right after the timed region (same inputs, same stream).  A long matmul is queued ahead of
+        # every step so that the step's launches wait in the queue and the events bracket back-to-back
+        # execution, not host launch latency.
+        roofline = None
+        if want_roofline and rank == 0:
+            timer.enabled = True
+            blk = torch.empty(4096, 8192, device=device)
+            blk_w = torch.empty(8192, 8192, device=device)
+            for i in range(min(steps, 20)):
+                if not big:
+                    torch.mm(blk, blk_w)
+                engine.eager_step(fresh[i % pool])
+            torch.cuda.synchronize()
+            timer.enabled = False
+    finally:
+        ops.gin_layer, ops.gin_layer_x6, ops.gin_layer_h3 = saved
+    pairs_per_step = batch * world
+    res = {"value": pairs_per_step / (elapsed / steps), "ms_per_step": 1e3 * elapsed / steps,
+           "timed_blocks": len(blocks), "ms_per_step_min": 1e3 * min(blocks) / steps,
+           "ms_per_step_max": 1e3 * max(blocks) / steps,
+           "config": {"workload": cfg["name"], "drugs": n_drugs, "atoms_per_gpu": Nn, "mol_edges_per_gpu": nnz,
+                      "interaction_pairs": int(len(ds.pair_gids)), "d": d, "pairs_per_step_per_gpu": batch,
+                      "pairs_per_step": pairs_per_step, "fresh_batch_every_step": True,
+                      "hip_graph": bool(engine.use_graph), "two_stream_overlap": bool(engine.overlap),
+                      "readout_with_upper": bool(engine.readout_with_upper),
+                      "lower_cus_per_xcd": engine.lower_cus_per_xcd, "fused_lower_stack": engine.fused is not None,
+                      "parallelism": "molecule shards x%d + all-gather(pooled) + pair shards" % world}}
+    if want_roofline and rank == 0:
+        ms, work, names = timer.result()
+        mode = max(set(names), key=names.count) if names else transform
+        mult, peak = MFMA_OF[mode]
         kname = {"f16x3": "k_gin_layer_h3 (fused GIN layer: CSR gather in LDS + 2 GEMMs as 3 fp16 MFMA products per "
                           "fp32 product + act/BN)",
                  "bf16x6": "k_gin_layer_x6 (fused GIN layer: CSR gather in LDS + 2 GEMMs as 6 bf16 MFMA products per "
                            "fp32 product + act/BN)",
                  "f32": "k_gin_layer (fused GIN layer: CSR gather in LDS + 2 exact-f32 MFMA GEMMs + act/BN)"}[mode]
-        # The binding roofline of the launch is whichever floor is higher: algorithmic bytes at the HBM
-        # peak, or EXECUTED matrix-core flops (3x / 6x / 1x the algorithmic fp32 flops) at the dense peak of
-        # the MFMA dtype.  f16x3 halves the matrix-core work of bf16x6, which leaves HBM as the floor at d=128.
-        exec_tflops = mfma_mult * tflops
-        mfma_frac, hbm_frac = exec_tflops / peak, alg_gbps / PEAK_HBM_GBPS
-        by_hbm = hbm_frac >= mfma_frac
-        roofline = {
-            "kernel": kname,
-            "bound": "hbm" if by_hbm else "mfma",
-            "achieved": alg_gbps if by_hbm else exec_tflops,
-            "peak": PEAK_HBM_GBPS if by_hbm else peak,
-            "unit": "GB/s" if by_hbm else "TFLOP/s",
-            "frac": hbm_frac if by_hbm else mfma_frac, "traffic": traffic,
-            "alg_bytes_per_launch": sum(w[1] for w in work) / max(len(work), 1),
-            "alg_flops_per_launch": sum(w[0] for w in work) / max(len(work), 1),
-            "launches": len(ms), "avg_us": 1e3 * sum(ms) / max(len(ms), 1),
-            "alg_hbm_GBps": alg_gbps, "alg_hbm_frac": hbm_frac,
-            "executed_mfma_tflops": exec_tflops, "executed_mfma_frac": mfma_frac, "mfma_peak_tflops": peak,
-            "algorithmic_f32_tflops": tflops, "frac_of_f32_mfma_peak": tflops / PEAK_F32_MFMA_TFLOPS}
-        out = {
-            "metric": "DDI edge-pairs/sec (bi-level forward)",
-            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"f16x3": "f32 (dense transforms as f16x3 split MFMA, fp32-equivalent)",
-                      "bf16x6": "f32 (dense transforms as bf16x6 split MFMA, fp32-equivalent)", "f32": "f32"}[mode],
-            "data": "synthetic",
-            "config": {"workload": "DrugBank-shape DDI, lower GIN x5 + upper GAT x3, d=128, "
-                                   "batch=4096 edge pairs per GPU (BASELINE configs[1])",
-                       "drugs_per_gpu": DRUGS_PER_GPU, "atoms_per_gpu": Nn, "mol_edges_per_gpu": nnz,
-                       "interaction_pairs": int(len(ds.pair_gids)), "d": D,
-                       "pairs_per_step_per_gpu": BATCH_PAIRS, "hip_graph": bool(use_graph),
-                       "two_stream_overlap": bool(engine.overlap),
-                       "readout_with_upper": bool(engine.readout_with_upper),
-                       "lower_cus_per_xcd": engine.lower_cus_per_xcd,
-                       "fused_lower_stack": engine.fused is not None,
-                       "parallelism": "molecule/pair shards x%d + all-gather(pooled)" % world},
-            "roofline": roofline,
-        }
-        if not args.no_extra:
-            out["extra"] = micro_roofline(device)
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ds, flags, model, lower_batch, upper_batches[0], args.cpu_seconds)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        tag = {"f16x3": "gin_layer_h3", "bf16x6": "gin_layer_x6", "f32": "gin_layer"}[mode]
+        sel = [i for i, n in enumerate(names) if n == mode]
+        roofline = roofline_of(kname, [ms[i] for i in sel], [work[i] for i in sel], mult, peak,
+                               pmc_traffic(tag + ("_cfg%d" % cfg_id if cfg_id != 1 else "")))
+        res["roofline"] = roofline
+    engine.close()
+    res["_cpu"] = lambda seconds: cpu_baseline_bilevel(ds, flags, model, lower_batch, template, batch, seconds)
+    return res
 
 
+def cpu_baseline_bilevel(ds, flags, model, lower_batch, upper_batch, batch, seconds):
+    """The CPU oracle (pure PyTorch restatement of the reference path) on the host cores, same workload, same
+    weights; bounded sample.  Small molecule sets: whole steps.  Large ones (config 3): the lower sweep is
+    timed on a 1/64 sample of this rank's molecules and scaled, the interaction level runs in full."""
+    import numpy as np
+    import torch
+    import oracle
+    import helpers
+    from blgnn.batch import BatchData
+    from blgnn.forward import all_molecule_pairs
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    specs = helpers.layer_specs(flags)
+    k = flags.last_lower_lyr_num
+    sd = helpers.state_dict_cpu(model)
+    of = helpers.oracle_flags(flags, ds)
+    gids = lower_batch._graph_gids
+    frac = 1
+    if len(gids) > 8000:
+        frac = 64
+        sub = gids[:max(2, len(gids) // frac)]
+        lower_batch = BatchData(all_molecule_pairs(sub), ds, is_train=False, ignore_pairs=True)
+    pl = helpers.plain_batch(lower_batch, ds)
+    ids = torch.as_tensor(np.vectorize(ds.gs_map.get)(upper_batch.batch_gids))
+    ph0 = helpers.plain_batch(upper_batch, ds, with_pairs=ids)     # static graph layouts built once
+    n, t_low, t_up = 0, 0.0, 0.0
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        while True:
+            p = dict(pl)
+            p["init_x"] = None
+            a = time.perf_counter()
+            oracle.run_layers(specs[:k + 1], sd, p, of)
+            b = time.perf_counter()
+            ph = dict(ph0)
+            ph["init_x"] = p["init_x"]
+            oracle.run_layers(specs[k + 1:], sd, ph, of, first=k + 1)
+            c = time.perf_counter()
+            t_low, t_up, n = t_low + (b - a), t_up + (c - b), n + 1
+            if time.perf_counter() - t0 > seconds or n >= 200:
+                break
+    dt = frac * t_low + t_up
+    what = "%d whole steps of the same workload" % n if frac == 1 else \
+        "%d steps: lower sweep on 1/%d of the molecules (time scaled by %d) + full interaction level" % (n, frac, frac)
+    return {"value": n * batch / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "%s (oracle, torch CPU fp32, %d threads), %.1f s of CPU work"
+                      % (what, cores, time.perf_counter() - t0)}
+
+
+# ---------------------------------------------------------------------------------------------------
+# GMN configs (2, 4): NodeEmbedding / GMNPropagator x3 over the merged pair batch -> readout -> scores
+# ---------------------------------------------------------------------------------------------------
+def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roofline=True):
+    import numpy as np
+    import torch
+    import blgnn
+    from blgnn import ops
+    from blgnn.batch import BatchData
+    cfg = CONFIGS[cfg_id]
+    world, rank, device = D.world, D.rank, D.device
+    emu = args.emulate_world if (args.emulate_world > 1 and world == 1) else 0
+    eff_world = emu or world
+    weak = cfg["scaling"] == "weak"
+    d = cfg["d"]
+    batch = cfg["batch"] if weak else cfg["batch"] // eff_world
+    seed = SEED + cfg_id + 1
+    ds = blgnn.make_synthetic(cfg["drugs"], cfg["pairs"], shape=cfg["shape"], seed=seed, device=device,
+                              num_edge_types=cfg["edge_types"])
+    flags = blgnn.make_flags("lower_level_gmn", dataset=cfg["dataset"], lower_level_gnn_type="gin", D_lower=d,
+                             device=device, batch_size=batch, feature_transform=transform)
+    blgnn.set_flags(flags)
+    torch.manual_seed(seed)
+    data = blgnn.TrainData(ds, device=device, num_hyper_edge_feat=3 if cfg["edge_types"] > 1 else 0)
+    ds.init_interaction_graph_feats(flags.init_embds, device, flags.d_init)
+    model = blgnn.Model(data)
+    perturb_bn(model, seed + 1)
+    model.to(device).eval()
+    layers = list(model.layers[:-1])                       # ... LinkPred (no Loss)
+
+    # pre-built pair batches, resident in HBM (merged graph, CSR, segment offsets); each rank draws its own
+    rng = np.random.default_rng(seed + 17 + rank)
+    nb = 4
+    batches = []
+    for _ in range(nb):
+        b = BatchData(ds.pair_gids[rng.choice(len(ds.pair_gids), size=batch, replace=False)], ds,
+                      is_train=False, unique_graphs=False)
+        b.merge_data['merge'].csr()
+        b.merge_data['merge'].segments()
+        batches.append(b)
+    Nn = int(np.mean([b.merge_data['merge'].x.shape[0] for b in batches]))
+    nnz = int(np.mean([b.merge_data['merge'].edge_index.shape[1] for b in batches]))
+
+    # dominant kernel: the dense transforms of the propagator (f_message / f_node GEMMs, M = all atoms)
+    timer = KernelTimer()
+    saved = ops.linear
+    min_rows = Nn // 2
+
+    def lin_work(x, w_kn, *a, **kw):
+        M, K = x.shape
+        N = w_kn.shape[1]
+        return (2.0 * M * N * K, 4.0 * M * (K + N) + 4.0 * K * N)
+    ops.linear = timer.wrap(transform, saved, lin_work, lambda x, w_kn, *a, **kw: x.shape[0] >= min_rows)
+    import blgnn.layers_gmn as _lg
+    import blgnn.layers_util as _lu
+    assert _lg.ops is ops and _lu.ops is ops               # the modules call ops.linear through the module
+
+    def forward(i):
+        b = batches[i % nb]
+        model.acts = [b.merge_data['merge'].x]
+        with torch.no_grad():
+            for layer in layers:
+                model.acts.append(layer(model.acts[-1], b, model))
+        return model.acts[-1]
+    try:
+        last = [None]
+
+        def one(i):
+            last[0] = forward(i)
+        for i in range(warmup):
+            one(i)
+        run_block, counter = block_runner(D, one, torch.cuda.synchronize, steps)
+        counter[0] = warmup
+        elapsed, blocks = timed_blocks(run_block, min_seconds)
+        preds = last[0]
+        assert preds.shape[0] == batch and bool(torch.isfinite(preds).all())
+        if want_roofline and rank == 0:
+            timer.enabled = True
+            for i in range(min(steps, 8)):
+                forward(i)
+            torch.cuda.synchronize()
+            timer.enabled = False
+    finally:
+        ops.linear = saved
+    pairs_per_step = batch * world
+    res = {"value": pairs_per_step / (elapsed / steps), "ms_per_step": 1e3 * elapsed / steps,
+           "timed_blocks": len(blocks), "ms_per_step_min": 1e3 * min(blocks) / steps,
+           "ms_per_step_max": 1e3 * max(blocks) / steps,
+           "config": {"workload": cfg["name"], "drugs": cfg["drugs"], "atoms_per_gpu": Nn, "mol_edges_per_gpu": nnz,
+                      "interaction_pairs": int(len(ds.pair_gids)), "d": d, "pairs_per_step_per_gpu": batch,
+                      "pairs_per_step": pairs_per_step, "molecule_instances_per_gpu": 2 * batch,
+                      "distinct_batches_cycled": nb, "output_logits": int(preds.shape[1]),
+                      "parallelism": "pair shards x%d, no collective (pairs are independent)" % world}}
+    if want_roofline and rank == 0:
+        ms, work, names = timer.result()
+        mult, peak = MFMA_OF[transform]
+        kname = {"f16x3": "k_linear_h3 (f_message / f_node GEMMs of the GMN propagator over all atoms: 3 fp16 MFMA "
+                          "products per fp32 product, row-normalised operands, act/BN epilogue)",
+                 "bf16x6": "k_linear_x6 (f_message / f_node GEMMs of the GMN propagator over all atoms: 6 bf16 MFMA "
+                           "products per fp32 product, act/BN epilogue)",
+                 "f32": "k_linear (f_message / f_node GEMMs of the GMN propagator, exact-f32 MFMA)"}[transform]
+        tag = {"f16x3": "linear_h3", "bf16x6": "linear_x6", "f32": "linear"}[transform]
+        res["roofline"] = roofline_of(kname, ms, work, mult, peak, pmc_traffic(tag + "_cfg%d" % cfg_id))
+    res["_cpu"] = lambda seconds: cpu_baseline_gmn(ds, flags, model, batch, seconds, seed)
+    return res
+
+
+def cpu_baseline_gmn(ds, flags, model, batch, seconds, seed):
+    """The CPU oracle on a bounded sample of the same workload: pair batches of 256 pairs drawn like the
+    GPU's (the forward is linear in the number of pairs: every pair is an independent component)."""
+    import numpy as np
+    import torch
+    import oracle
+    import helpers
+    from blgnn.batch import BatchData
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    specs = helpers.layer_specs(flags)
+    sd = helpers.state_dict_cpu(model)
+    of = helpers.oracle_flags(flags, ds)
+    rng = np.random.default_rng(seed + 99)
+    sub = min(256, batch)
+    n = 0
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        while True:
+            b = BatchData(ds.pair_gids[rng.choice(len(ds.pair_gids), size=sub, replace=False)], ds,
+                          is_train=False, unique_graphs=False)
+            ids = torch.arange(2 * sub).view(sub, 2)
+            oracle.run_layers(specs, sd, helpers.plain_batch(b, ds, with_pairs=ids), of)
+            n += 1
+            if time.perf_counter() - t0 > seconds or n >= 200:
+                break
+    dt = time.perf_counter() - t0
+    return {"value": n * sub / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d forwards of %d-pair batches of the same workload (oracle, torch CPU fp32, %d threads; "
+                      "includes its per-pair python loop for f_match as the reference has), %.1f s"
+                      % (n, sub, cores, dt)}
+
+
+# ---------------------------------------------------------------------------------------------------
+# extras
+# ---------------------------------------------------------------------------------------------------
 def micro_roofline(device):
     """North-star kernel evidence: molecular SpMM (GIN aggregation) and segment-mean readout at
     d=256 on a 12 500-molecule x ~40-atom shard (BASELINE configs[3] per-GPU share), HIP-event
     timed; algorithmic bytes per SURVEY section 8(d)."""
+    import torch
     import blgnn
     from blgnn import ops
-    ds = blgnn.make_synthetic(12500, 10, shape="atoms40", seed=SEED + 100, device=device)
+    ds = blgnn.make_synthetic(12500, 10, shape="atoms40", seed=SEED + 102, device=device)
     m = ds.molecules.merge(ds.molecules.gids)["merge"]
     n, nnz, G, d = m.x.shape[0], m.edge_index.shape[1], m.num_graphs, 256
     x = torch.randn(n, d, device=device)
@@ -352,73 +681,80 @@ def micro_roofline(device):
     t = timeit(lambda: ops.spmm_sum(csr, x, 1.0, True, out=y))
     b = 4.0 * d * n * 2 + 4.0 * nnz + 4.0 * (n + 1)
     res["spmm_d256"] = {"bound": "hbm", "achieved": b / t / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                        "frac": b / t / 1e9 / PEAK_HBM_GBPS, "alg_bytes": b, "us": t * 1e6}
+                        "frac": b / t / 1e9 / PEAK_HBM_GBPS, "alg_bytes": b, "us": t * 1e6,
+                        "traffic": pmc_traffic("spmm_d256")}
     t = timeit(lambda: ops.segment_reduce(seg, x, "mean", out=pooled))
     b = 4.0 * d * n + 4.0 * d * G + 4.0 * (G + 1)
     res["readout_d256"] = {"bound": "hbm", "achieved": b / t / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                           "frac": b / t / 1e9 / PEAK_HBM_GBPS, "alg_bytes": b, "us": t * 1e6}
-    w = torch.randn(d, d, device=device) / 16
-    h = torch.empty_like(x)
-    t = timeit(lambda: ops.linear(x, w, out=h, transform="f32"), reps=10)
-    f = 2.0 * n * d * d
-    res["linear_d256"] = {"bound": "mfma", "achieved": f / t / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
-                          "unit": "TFLOP/s", "frac": f / t / 1e12 / PEAK_F32_MFMA_TFLOPS, "us": t * 1e6}
-    # same GEMM as six bf16 MFMA products per fp32 product: executed rate against the bf16 peak, and
-    # the launch against HBM (X read once, Y written once)
-    t = timeit(lambda: ops.linear(x, w, out=h, transform="bf16x6"), reps=10)
-    by = 8.0 * n * d
-    res["linear_d256_bf16x6"] = {"bound": "mfma", "achieved": 6.0 * f / t / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS,
-                                 "unit": "TFLOP/s", "frac": 6.0 * f / t / 1e12 / PEAK_BF16_MFMA_TFLOPS,
-                                 "algorithmic_f32_tflops": f / t / 1e12, "alg_hbm_GBps": by / t / 1e9,
-                                 "alg_hbm_frac": by / t / 1e9 / PEAK_HBM_GBPS, "us": t * 1e6}
+                           "frac": b / t / 1e9 / PEAK_HBM_GBPS, "alg_bytes": b, "us": t * 1e6,
+                           "traffic": pmc_traffic("readout_d256")}
     return res
 
 
-def usable_cores():
-    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota
-    (a 1-GPU box exposes all 256 hardware threads but grants a share of them)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
-    except (OSError, ValueError):
-        pass
-    return max(1, min(n, 64))
+def rendezvous_only(args):
+    """Launcher rehearsal for boxes without N GPUs (tests/test_dist_cpu.py): the ranks meet over gloo,
+    count themselves, rank 0 prints the result line's envelope with ``n_gpus`` = ranks that joined and
+    ``value`` null.  Nothing is measured and no kernel runs."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    joined = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(joined)
+    if os.environ.get("BLGNN_BENCH_FAIL_RANK") == str(rank):
+        raise SystemExit("rank %d: injected failure" % rank)
+    if rank == 0:
+        print(json.dumps({"metric": "DDI edge-pairs/sec (bi-level forward)", "value": None, "unit": "pairs/s",
+                          "n_gpus": int(joined.item()), "steps": args.steps, "warmup": args.warmup,
+                          "rendezvous_only": True, "scaling": CONFIGS[args.config]["scaling"],
+                          "config": {"workload": CONFIGS[args.config]["name"]}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
-def cpu_baseline(ds, flags, model, lower_batch, upper_batch, seconds):
-    """The CPU oracle (pure PyTorch restatement of the reference path) on the host cores, same
-    workload, same weights; bounded sample of whole steps."""
-    import oracle
-    import helpers
-    cores = usable_cores()
-    torch.set_num_threads(cores)
-    specs = helpers.layer_specs(flags)
-    k = flags.last_lower_lyr_num
-    sd = helpers.state_dict_cpu(model)
-    of = helpers.oracle_flags(flags, ds)
-    pl = helpers.plain_batch(lower_batch, ds)
-    ids = torch.as_tensor(np.vectorize(ds.gs_map.get)(upper_batch.batch_gids))
-    ph0 = helpers.plain_batch(upper_batch, ds, with_pairs=ids)     # static graph layouts built once
-    n = 0
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        while True:
-            p = dict(pl)
-            p["init_x"] = None
-            oracle.run_layers(specs[:k + 1], sd, p, of)
-            ph = dict(ph0)
-            ph["init_x"] = p["init_x"]
-            oracle.run_layers(specs[k + 1:], sd, ph, of, first=k + 1)
-            n += 1
-            if time.perf_counter() - t0 > seconds or n >= 200:
-                break
-    dt = time.perf_counter() - t0
-    return {"value": n * BATCH_PAIRS / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d whole steps of the same workload (oracle, torch CPU fp32, %d threads), %.1f s"
-                      % (n, cores, dt)}
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
+    if os.environ.get("BLGNN_BENCH_RENDEZVOUS_ONLY"):
+        return rendezvous_only(args)
+    import torch                                            # noqa: F401  (first GPU-touching import of a rank)
+    D = Dist(args)
+    transform = "f32" if args.exact_f32 else args.transform
+    cfg = CONFIGS[args.config]
+    runner = run_bilevel if cfg["kind"] == "bilevel" else run_gmn
+    res = runner(args.config, args, D, transform, args.steps, args.warmup, args.min_seconds)
+    if D.rank == 0:
+        out = {"metric": "DDI edge-pairs/sec (bi-level forward)",
+               "value": res["value"], "unit": "pairs/s", "n_gpus": D.world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+               "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
+               "dtype": DTYPE_OF[transform], "data": "synthetic",
+               "timing": {"blocks_of_K_steps": res["timed_blocks"], "reported": "median block",
+                          "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"]},
+               "config": dict(res["config"], baseline_config_index=args.config),
+               "roofline": res.get("roofline")}
+        if not args.no_extra and D.world == 1:
+            extra = {}
+            if args.config != 1:
+                # the round-1 headline configuration, for comparability across rounds
+                r1 = run_bilevel(1, args, D, transform, 50, 10, 0.3, want_roofline=True)
+                extra["configs_1"] = {"value": r1["value"], "unit": "pairs/s", "ms_per_step": r1["ms_per_step"],
+                                      "workload": r1["config"]["workload"], "roofline": r1.get("roofline")}
+            extra.update(micro_roofline(D.device))
+            out["extra"] = extra
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = res["_cpu"](args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    D.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

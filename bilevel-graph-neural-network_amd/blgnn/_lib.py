@@ -55,11 +55,14 @@ SIGNATURES = {
     "blgnn_linear": [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p, _p],
     "blgnn_gat_transform": [_p, _i64, _p, _i64, _p, _i32, _i32, _i32, _p, _i64, _p, _p, _p],
     "blgnn_linear_x6": [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p, _p],
+    "blgnn_linear_h3": [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p, _p],
     "blgnn_gmn_match": [_p, _i32, _p, _i64, _p, _i64, _i32, _p],
     "blgnn_pair_gather_normalize": [_p, _i64, _p, _p, _i32, _i32, _f32, _p, _i64, _p],
     "blgnn_link_pred_head": [_p, _i64, _p, _p, _i32, _i32, _f32, _i32, _p, _p, _p, _i32, _i32, _p, _i64, _p],
     "blgnn_l2_normalize_rows": [_p, _i64, _p, _i64, _i32, _i32, _f32, _p],
     "blgnn_scatter_rows": [_p, _i64, _p, _p, _i64, _i32, _i32, _p],
+    "blgnn_stream_create_cu_mask": [_p, _i32, _p],
+    "blgnn_stream_destroy": [_p],
 }
 LIBRARY_SYMBOLS = ["blgnn_version", "blgnn_last_error", "blgnn_device_count", "blgnn_packed_weight_x6_elems",
                    "blgnn_packed_weight_h3_elems"]

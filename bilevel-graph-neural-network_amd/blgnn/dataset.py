@@ -20,6 +20,7 @@ from .graph import MoleculeStore, InteractionGraph
 __all__ = ["BiGNNDataset", "TrainData", "make_synthetic", "one_hot_from_codes", "FEATURE_CARDS"]
 
 FEATURE_CARDS = (32, 2, 2, 2, 7, 7)     # atom_type, aromatic, acceptor, donor, hybridization, num_h
+DRUGCOMBO_CARDS = (20, 2, 2, 2, 7, 7)   # F_in = 40 (DrugCombo one-hot width)
 
 
 class BiGNNDataset(object):
@@ -132,6 +133,9 @@ def _molecule_sizes(rng, G, shape):
         return np.clip(n, 2, 457).astype(np.int64)
     if shape == "atoms40":
         return np.clip(np.rint(rng.normal(40.0, 10.0, size=G)), 4, 160).astype(np.int64)
+    if shape == "drugcombo":                                  # 3 376 molecules, mean 29.3 atoms, max 155
+        n = np.rint(rng.lognormal(mean=math.log(26.5), sigma=0.45, size=G))
+        return np.clip(n, 2, 155).astype(np.int64)
     raise ValueError(shape)
 
 
@@ -162,9 +166,9 @@ def _molecule_edges(rng, sizes):
     return np.stack([u, v]), node_ptr, edge_ptr
 
 
-def _atom_codes(rng, A):
+def _atom_codes(rng, A, cards=FEATURE_CARDS):
     cols = []
-    for c in FEATURE_CARDS:
+    for c in cards:
         p = 1.0 / np.arange(1, c + 1) ** 1.6                 # Zipf-like: C >> N, O > others
         cols.append(rng.choice(c, size=A, p=p / p.sum()))
     return np.stack(cols, axis=1).astype(np.int64)
@@ -194,8 +198,9 @@ def make_synthetic(num_drugs, num_pairs, shape="drugbank", seed=20200614, device
     rng = np.random.Generator(np.random.PCG64(seed))
     sizes = _molecule_sizes(rng, num_drugs, shape)
     edge_local, node_ptr, edge_ptr = _molecule_edges(rng, sizes)
-    codes = _atom_codes(rng, int(node_ptr[-1]))
-    x = one_hot_from_codes(codes, device=device)
+    cards = DRUGCOMBO_CARDS if shape == "drugcombo" else FEATURE_CARDS
+    codes = _atom_codes(rng, int(node_ptr[-1]), cards)
+    x = one_hot_from_codes(codes, cards=cards, device=device)
     store = MoleculeStore(x, edge_local, node_ptr, edge_ptr, range(num_drugs), device)
     max_pairs = num_drugs * (num_drugs - 1) // 2
     pairs = _chung_lu_edges(rng, num_drugs, min(num_pairs, max_pairs))

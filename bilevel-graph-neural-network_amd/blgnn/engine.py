@@ -8,6 +8,11 @@ interaction-level pass and the pair scorer of step k (stream U) are still in fli
 halves meet through events and a double-buffered ``init_x`` (step parity selects the buffer),
 so no kernel ever reads a buffer another in-flight step is writing.
 
+The pair batch is DATA, not structure: the upper graph reads the rows it scores from a static
+``[2, B]`` int64 device buffer per parity, which ``step(pairs)`` fills with one asynchronous
+host-to-device copy, so ONE captured graph serves every batch the sampler produces
+(src/sampler.py:120-131 hands the reference a fresh ``[B, 2]`` gid batch per iteration).
+
 What runs where mirrors src/train.py:75-108 of the reference: ``lower`` = ``_get_initial_embd``
 (every molecule through the lower layers + readout, rows written into the interaction
 graph's ``init_x``), ``exchange`` = the all-gather that replaces those row writes across
@@ -113,6 +118,10 @@ class FusedLowerStack(object):
 
 
 class BiLevelEngine(object):
+    """``upper_batches``: one ``BatchData`` (the template whose layout every scored batch shares: B
+    pairs, evaluation mode) or a list of them; ``step(i)`` with an int scores list entry ``i % len``,
+    ``step(pairs)`` with an int array ``[B, 2]`` of graph ids scores those pairs."""
+
     def __init__(self, model, lower_batch, upper_batches, graph, sharded=None, world_size=1,
                  use_graph=True, overlap=True, fuse_lower=False, readout_with_upper=None, lower_cus_per_xcd=None):
         from .config import FLAGS
@@ -120,19 +129,41 @@ class BiLevelEngine(object):
         self.model = model
         self.lower_layers = list(model.layers[:k + 1])
         self.upper_layers = list(model.layers[k + 1:-1])      # LoadInteraction ... LinkPred (no Loss)
-        self.lower_batch, self.upper_batches = lower_batch, upper_batches
+        if isinstance(upper_batches, BatchData):
+            upper_batches = [upper_batches]
+        self.lower_batch, self.upper_batches = lower_batch, list(upper_batches)
         self.graph, self.sharded, self.world = graph, sharded, world_size
         self.use_graph = use_graph
         self.overlap = overlap and use_graph
-        self.nb = len(upper_batches)
+        self.nb = len(self.upper_batches)
         self.parities = 2 if self.overlap else 1
         dev = lower_batch.merge_data['merge'].x.device
+        self.device = dev
         base = graph.init_x
         self.init_x = [base] + [torch.zeros_like(base) for _ in range(self.parities - 1)]
         self.pooled = [None] * self.parities
         self.g_lower = [None] * self.parities
-        self.g_upper = [[None] * self.nb for _ in range(self.parities)]
-        self.outs = [[None] * self.nb for _ in range(self.parities)]
+        self.g_upper = [None] * self.parities
+        self.outs = [None] * self.parities
+        # ---- the pair batch as data: row ids of the pairs in pinned host memory and static device buffers
+        self.template = self.upper_batches[0]
+        pred = self.upper_layers[-1]
+        host = [np.ascontiguousarray(pred.pair_row_ids(b).T) for b in self.upper_batches]      # [2, B] each
+        self.B = int(host[0].shape[1])
+        if any(h.shape != (2, self.B) for h in host):
+            raise ValueError("blgnn: every upper batch of an engine must score the same number of pairs")
+        self.host_ids = [torch.as_tensor(h).pin_memory() for h in host]
+        self.stage_ids = [torch.empty((2, self.B), dtype=torch.int64).pin_memory() for _ in range(self.parities)]
+        self.ids_dev = [torch.zeros((2, self.B), dtype=torch.int64, device=dev) for _ in range(self.parities)]
+        ds = self.template.dataset
+        table = ds.gs_map if FLAGS.higher_level_layers else None
+        self._row_lut = None
+        if table is not None and pred.batch_unique_graphs:
+            keys = np.fromiter(table.keys(), dtype=np.int64, count=len(table))
+            if keys.size and keys.min() >= 0 and keys.max() < 8 * keys.size + 1024:
+                lut = np.full(int(keys.max()) + 1, -1, dtype=np.int64)
+                lut[keys] = np.fromiter(table.values(), dtype=np.int64, count=len(table))
+                self._row_lut = lut
         gids = lower_batch._graph_gids
         self.fused = None
         if fuse_lower and FusedLowerStack.supported(self.lower_layers, FLAGS) and \
@@ -155,16 +186,61 @@ class BiLevelEngine(object):
         self.stream_l = torch.cuda.Stream(device=dev) if self.overlap else None
         self.stream_u = torch.cuda.Stream(device=dev) if self.overlap else None
         self.lower_cus_per_xcd = None
+        self._masked = None
         if self.overlap and lower_cus_per_xcd:
-            # each half of the step on its own compute units (blgnn/streams.py)
+            # each half of the step on its own compute units (blgnn/streams.py); the engine owns the pair
             from .streams import cu_partition_streams
             pair = cu_partition_streams(dev, lower_cus_per_xcd)
             if pair is not None:
-                self.stream_l, self.stream_u = pair
-                self.lower_cus_per_xcd = int(lower_cus_per_xcd)
+                self._masked = pair
+                self.stream_l, self.stream_u = pair.first, pair.second
+                self.lower_cus_per_xcd = pair.cus
+        # exchange buffers (N > 1): padded send block, gathered blocks, row index that undoes the padding
+        self._xchg = None
+        if self.world > 1:
+            counts = [int(c) for c in sharded.counts]
+            cmax, D = max(counts), base.shape[1]
+            src = np.concatenate([r * cmax + np.arange(c, dtype=np.int64) for r, c in enumerate(counts)])
+            self._xchg = {"send": [torch.zeros((cmax, D), dtype=torch.float32, device=dev) for _ in range(self.parities)],
+                          "recv": [torch.empty((self.world * cmax, D), dtype=torch.float32, device=dev)
+                                   for _ in range(self.parities)],
+                          "rows": torch.as_tensor(src).to(dev), "even": all(c == cmax for c in counts)}
         self.ev_lower = [None] * self.parities
         self.ev_upper = [None] * self.parities
         self.step_no = 0
+        self._stamp = None
+        self._closed = False
+
+    # ---- weights watched for in-place changes after capture -----------------------------------
+    def _weights_stamp(self):
+        ts = list(self.model.parameters()) + list(self.model.buffers())
+        return (sum(t._version for t in ts), tuple(t.data_ptr() for t in ts))
+
+    # ---- pair ids ---------------------------------------------------------------------------------
+    def rows_of(self, pair_gids):
+        """[B, 2] graph ids -> [2, B] int64 rows of the tensor LinkPred reads (gs_map lookup, vectorised)."""
+        g = np.asarray(pair_gids, dtype=np.int64).reshape(-1, 2)
+        if g.shape[0] != self.B:
+            raise ValueError("blgnn: this engine scores %d pairs per step, got %d" % (self.B, g.shape[0]))
+        if self._row_lut is not None:
+            rows = self._row_lut[g]
+            if (rows < 0).any():
+                raise KeyError("unknown graph id in pair batch")
+            return np.ascontiguousarray(rows.T)
+        b = BatchData(g, self.template.dataset, is_train=False)
+        return np.ascontiguousarray(self.upper_layers[-1].pair_row_ids(b).T)
+
+    def _feed(self, which, parity):
+        """Asynchronous H2D copy of one batch's row ids into the parity's static buffer (on the
+        current stream).  ``which``: list index or [B, 2] graph ids."""
+        if isinstance(which, (int, np.integer)):
+            src = self.host_ids[int(which) % self.nb]
+        else:
+            if self.ev_upper[parity] is not None:             # the staging buffer's previous copy has run
+                self.ev_upper[parity].synchronize()
+            src = self.stage_ids[parity]
+            src.copy_(torch.from_numpy(self.rows_of(which)))
+        self.ids_dev[parity].copy_(src, non_blocking=True)
 
     # ---- the three pieces of one forward -------------------------------------------------
     def lower(self, parity=0, readout=True):
@@ -185,34 +261,49 @@ class BiLevelEngine(object):
             return self.init_x[parity][self.local_lo:self.local_hi]
 
     def exchange(self, pooled, parity=0):
-        if self.world > 1:                                     # the one collective of the path
-            self.sharded.gather_init_x(pooled.clone(), out=self.init_x[parity])
+        """The one collective of the path: all-gather of the pooled drug rows (padded to the largest
+        shard) into persistent buffers, then ONE row gather that drops the padding into init_x."""
+        if self.world <= 1:
+            return
+        import torch.distributed as dist
+        x = self._xchg
+        send, recv = x["send"][parity], x["recv"][parity]
+        send[:pooled.shape[0]].copy_(pooled)
+        dist.all_gather_into_tensor(recv, send, group=self.sharded.group)
+        if x["even"]:
+            self.init_x[parity].copy_(recv)
+        else:
+            torch.index_select(recv, 0, x["rows"], out=self.init_x[parity])
 
-    def upper(self, i, parity=0, readout=False):
+    def upper(self, parity=0, readout=False):
+        """Interaction-level layers + pair scorer on the rows in ``ids_dev[parity]``."""
         self.graph.init_x = self.init_x[parity]
         with torch.no_grad():
-            m, b = self.model, self.upper_batches[i % self.nb]
+            m, b = self.model, self.template
             if readout:                                        # the sweep's readout, deferred to this graph
                 m.acts = list(self.lower_acts[parity])
                 self.lower_layers[-1](m.acts[-1], self.lower_batch, m)
+            b._pair_row_ids = (self.ids_dev[parity][0], self.ids_dev[parity][1])
             m.acts = [b.merge_data['merge'].x]
             for layer in self.upper_layers:
                 m.acts.append(layer(m.acts[-1], b, m))
             return m.acts[-1]
 
-    def eager_step(self, i):
+    def eager_step(self, which):
+        self._feed(which, 0)
         self.exchange(self.lower(0), 0)
-        return self.upper(i, 0)
+        return self.upper(0)
 
     # ---- capture ------------------------------------------------------------------------------
     def capture(self):
-        """Run every batch once eagerly (host->device id copies and CSR builds must not fall
-        into a capture), then record the graphs."""
+        """Run once eagerly per parity (CSR builds and derived-weight packing must not fall into a
+        capture), then record the graphs."""
         for p in range(self.parities):
-            for i in range(self.nb):
-                self.exchange(self.lower(p), p)
-                self.upper(i, p)
+            self._feed(0, p)
+            self.exchange(self.lower(p), p)
+            self.upper(p)
         torch.cuda.synchronize()
+        self._stamp = self._weights_stamp()
         if not self.use_graph:
             return
         side = torch.cuda.Stream()
@@ -224,24 +315,33 @@ class BiLevelEngine(object):
                 with torch.cuda.graph(g, stream=side):
                     self.pooled[p] = self.lower(p, readout=not defer)
                 self.g_lower[p] = g
-                for i in range(self.nb):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=side):
-                        self.outs[p][i] = self.upper(i, p, readout=defer)
-                    self.g_upper[p][i] = g
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    self.outs[p] = self.upper(p, readout=defer)
+                self.g_upper[p] = g
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
 
     # ---- steady state ---------------------------------------------------------------------------
-    def step(self, i):
-        """Enqueue forward number ``i`` (asynchronous); returns the tensor its pair scores land in."""
+    def step(self, which):
+        """Enqueue one forward (asynchronous); ``which`` = index into the batch list or a [B, 2] array
+        of graph ids.  Returns the tensor the pair scores land in (valid once the step has run; it is
+        reused two steps later)."""
+        if self._closed:
+            raise RuntimeError("blgnn: engine is closed")
         if not self.use_graph:
-            return self.eager_step(i)
+            return self.eager_step(which)
+        if self._weights_stamp() != self._stamp:
+            # weights / BN statistics changed after capture: the graphs hold pointers to tensors derived
+            # from the old values (packed images, folded affines).  Re-derive and re-capture.
+            self.synchronize()
+            self.capture()
         if not self.overlap:
+            self._feed(which, 0)
             self.g_lower[0].replay()
             self.exchange(self.pooled[0], 0)
-            self.g_upper[0][i % self.nb].replay()
-            return self.outs[0][i % self.nb]
+            self.g_upper[0].replay()
+            return self.outs[0]
         p = self.step_no & 1
         self.step_no += 1
         cur = torch.cuda.current_stream()
@@ -255,15 +355,39 @@ class BiLevelEngine(object):
             self.ev_lower[p] = torch.cuda.Event()
             self.ev_lower[p].record(self.stream_l)
         with torch.cuda.stream(self.stream_u):
+            self._feed(which, p)                               # in order behind step k-2's upper graph
             self.stream_u.wait_event(self.ev_lower[p])
-            self.g_upper[p][i % self.nb].replay()
+            self.g_upper[p].replay()
             self.ev_upper[p] = torch.cuda.Event()
             self.ev_upper[p].record(self.stream_u)
-        return self.outs[p][i % self.nb]
+        return self.outs[p]
 
     def synchronize(self):
-        if self.overlap:
+        if self.overlap and self.stream_l is not None:
             cur = torch.cuda.current_stream()
             cur.wait_stream(self.stream_l)
             cur.wait_stream(self.stream_u)
         torch.cuda.synchronize()
+
+    def close(self):
+        """Drain the device, drop the captured graphs and destroy the CU-masked streams this engine
+        owns.  Idempotent; the engine cannot step afterwards."""
+        if self._closed:
+            return
+        self._closed = True
+        torch.cuda.synchronize()
+        self.g_lower = [None] * self.parities
+        self.g_upper = [None] * self.parities
+        self.ev_lower = [None] * self.parities
+        self.ev_upper = [None] * self.parities
+        self.stream_l = self.stream_u = None
+        if self._masked is not None:
+            self._masked.close()
+            self._masked = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False

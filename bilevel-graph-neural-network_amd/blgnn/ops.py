@@ -261,8 +261,8 @@ GAT_TRANSFORM_MAX_ROWS = 8192  # above this the transform is throughput bound: t
 LINEAR_X6_MIN_TILES = 256      # 128x128 output tiles; below one per CU the f32 kernels' smaller tiles win
 
 
-def _packed_weight(w_kn):
-    key = id(w_kn)
+def _packed_weight(w_kn, kind="x6"):
+    key = (id(w_kn), kind)
     hit = _PACKED.get(key)
     stamp = (w_kn.data_ptr(), w_kn._version, tuple(w_kn.shape), w_kn.stride(0))
     if hit is not None and hit[0]() is w_kn and hit[1] == stamp:
@@ -270,7 +270,7 @@ def _packed_weight(w_kn):
     if len(_PACKED) > 512:
         for k in [k for k, v in _PACKED.items() if v[0]() is None]:
             del _PACKED[k]
-    packed = pack_weight_x6(w_kn)
+    packed = pack_weight_h3(w_kn) if kind == "h3" else pack_weight_x6(w_kn)
     _PACKED[key] = (weakref.ref(w_kn), stamp, packed)
     return packed
 
@@ -284,8 +284,8 @@ def linear_x6_supported(x, w_kn):
 def linear(x, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn_shift=None,
            rowvec=None, rowvec_w=None, out=None, transform=None):
     """epi(x @ w_kn + bias [+ rowvec (x) rowvec_w]); w_kn is [K, N] row-major.
-    ``transform``: "bf16x6" (bf16 matrix cores, fp32-equivalent, large M only), "f32" (exact-f32
-    MFMA) or None = FLAGS.feature_transform."""
+    ``transform``: "f16x3" / "bf16x6" (16-bit matrix cores, fp32-equivalent, large M only), "f32"
+    (exact-f32 MFMA) or None = FLAGS.feature_transform."""
     xp, ldx = _mat(x, "x")
     wp, ldw = _mat(w_kn, "w")
     M, K = x.shape
@@ -297,7 +297,10 @@ def linear(x, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn
     if transform is None:
         transform = getattr(FLAGS, "feature_transform", "bf16x6")
     if transform in ("bf16x6", "f16x3") and K > 0 and N > 0 and linear_x6_supported(x, w_kn):
-        call("blgnn_linear_x6", xp, ldx, _packed_weight(w_kn).data_ptr(), yp, ldy, M, N, K, _vec(bias, "bias"),
+        # large-M GEMMs on the 16-bit matrix cores at fp32 accuracy: fp16 two-piece split (three MFMAs per
+        # product) or bf16 three-piece split (six)
+        name, kind = ("blgnn_linear_h3", "h3") if transform == "f16x3" else ("blgnn_linear_x6", "x6")
+        call(name, xp, ldx, _packed_weight(w_kn, kind).data_ptr(), yp, ldy, M, N, K, _vec(bias, "bias"),
              _vec(rowvec, "rowvec"), _vec(rowvec_w, "rowvec_w"), _act(act), _vec(act_param, "act_param"),
              _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), _stream())
         return y

@@ -2,7 +2,7 @@
 //
 // Every fp32 operand is split into TWO fp16 pieces x = h1 + h2 (11 + 11 significand bits; the
 // representation error is 2^-23 |x|, fp32's own half-ulp) and a product a*w is the three fp16 MFMAs
-// a1*w1 + a1*w2 + a2*w1, accumulated in fp32; the dropped a2*w2 is below 2^-24 |a||w|.  Against the
+// a1*w1 + a1*w2 + a2*w1, accumulated in fp32; the dropped a2*w2 is at most 2^-22 |a||w|.  Against the
 // three-piece bf16 scheme (gin_x6.hip) this is half the matrix-core work and two thirds of the
 // operand bytes in LDS and of the weight-fragment traffic (the 32-row kernels are bound by that
 // traffic: 196 KB of bf16 fragments per tile through a 64 B/clk L1 fill path), and the smaller
@@ -20,32 +20,11 @@
 // act + eval-BN -> row stores; GEMMs transposed (weight fragment = MFMA A operand) so a lane owns
 // four consecutive output columns of one row.
 #include "gin_common.hpp"
-#include "x6_common.hpp"
+#include "h3_common.hpp"
 
 namespace blgnn {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4h __attribute__((ext_vector_type(4)));
-
 constexpr int HCOLS = 512;       // column indices of a tile kept in LDS (64 rows x mean degree 2.1 = 136)
-constexpr int HHDR = 8;          // packed image header, in fp16 elements (16 bytes): float inv_scale
-
-struct Split2 { _Float16 h1, h2; };
-__device__ __forceinline__ Split2 split2(float x) {
-    Split2 s;
-    s.h1 = (_Float16)x;
-    s.h2 = (_Float16)(x - (float)s.h1);
-    return s;
-}
-
-// power-of-two scale that moves a magnitude into [2^14, 2^15); returns (scale, 1 / scale)
-__device__ __forceinline__ void pow2_scale(float amax, float &scale, float &inv) {
-    unsigned e = (__float_as_uint(amax) >> 23) & 0xffu;          // biased exponent of the maximum
-    e = e < 32u ? 32u : (e > 222u ? 222u : e);                   // zeros / denormals / overflow guard
-    scale = __uint_as_float((268u - e) << 23);                    // 2^(14 - (e - 127))
-    inv = __uint_as_float((e - 14u) << 23);                       // 2^((e - 127) - 14)
-}
 
 // ---- weight packing: W[K,N] fp32 -> header + [2][Kp/8][N][8] fp16, scaled by a power of two -------------
 __global__ void k_absmax(const float *__restrict__ w, int64_t ldw, int K, int N, unsigned *out) {

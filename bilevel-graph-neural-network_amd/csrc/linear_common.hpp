@@ -28,9 +28,12 @@ __device__ __forceinline__ float act_c(float v, float slope) {
 }
 
 // One wave's TM x TN accumulator tiles -> y, 32 rows at a time through its private LDS tile.
+// ``rs`` (LDS, outside the staging tiles; indexed by row - row0) and ``cs`` undo the power-of-two
+// operand scaling of the f16x3 kernels: acc * rs[row] * cs before the bias.
 template <int ACT, int TM, int TN, int WN>
 __device__ __forceinline__ void store_out(const LinearArgs &A, const f32x16 (&acc)[TM][TN], float *smem,
-                                          int row0, int col0, int wid, int lane) {
+                                          int row0, int col0, int wid, int lane,
+                                          const float *rs = nullptr, float cs = 1.f) {
     constexpr int LDO = WN + 4;
     constexpr int Q = WN / 4;                            // float4 per staged row
     float *stage = smem + wid * 32 * LDO;
@@ -56,7 +59,9 @@ __device__ __forceinline__ void store_out(const LinearArgs &A, const f32x16 (&ac
             for (int r = 0; r < 16; ++r) {
                 const int lr = (r & 3) + 8 * (r >> 2) + 4 * fh;          // row inside the 32-row slab
                 const int m = row0 + 32 * i + lr;
-                float v = acc[i][j][r] + bias[j];
+                float v = acc[i][j][r];
+                if (rs) v = v * rs[32 * i + lr] * cs;
+                v += bias[j];
                 if (A.rowvec) v = fmaf((m < A.M) ? A.rowvec[m] : 0.f, rw[j], v);
                 v = act_c<ACT>(v, slope[j]);
                 if (A.epi.bn_scale) v = fmaf(v, scale[j], shift[j]);

@@ -1,4 +1,4 @@
-// Library-level entry points: version, thread-local error string, device probe.
+// Library-level entry points: version, thread-local error string, device probe, CU-masked streams.
 #include "common.hpp"
 #include <string.h>
 
@@ -35,4 +35,29 @@ extern "C" int blgnn_device_count(void) {
         if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
     }
     return ok;
+}
+
+// A HIP stream restricted to a set of compute units (the engine runs the molecular sweep and the
+// interaction level side by side on disjoint CUs).  Created and destroyed through the runtime this
+// library is linked against, on the device that is current for the calling thread.
+extern "C" int blgnn_stream_create_cu_mask(const uint32_t *mask_words_host, int32_t num_words, void **stream_out) {
+    BLGNN_CHECK_ARG(mask_words_host && num_words > 0 && stream_out, "stream_create_cu_mask: bad args");
+    hipStream_t s = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)num_words, mask_words_host);
+    if (e != hipSuccess || !s) {
+        (void)hipGetLastError();
+        return blgnn::fail(BLGNN_ERR_LAUNCH, "hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+    }
+    *stream_out = (void *)s;
+    return BLGNN_OK;
+}
+
+extern "C" int blgnn_stream_destroy(void *stream) {
+    BLGNN_CHECK_ARG(stream, "stream_destroy: null stream");
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return blgnn::fail(BLGNN_ERR_LAUNCH, "hipStreamDestroy: %s", hipGetErrorString(e));
+    }
+    return BLGNN_OK;
 }

@@ -63,6 +63,14 @@ const char *blgnn_last_error(void);
 /* number of visible gfx950 devices; 0 on a box without one (never negative) */
 int         blgnn_device_count(void);
 
+/* HIP stream restricted to the compute units whose bits are set in mask_words_host (num_words x 32
+ * bits; on MI355X bit i = CU i / 8 of XCD i % 8), on the calling thread's current device.  The
+ * reference runs everything on one stream (src/train.py:75-108); the engine runs the molecular sweep
+ * and the interaction-level pass of consecutive forwards side by side on disjoint CUs.  The caller
+ * owns the stream and releases it with blgnn_stream_destroy after synchronising it. */
+int blgnn_stream_create_cu_mask(const uint32_t *mask_words_host, int32_t num_words, void **stream_out);
+int blgnn_stream_destroy(void *stream);
+
 /* ---- graph layout ------------------------------------------------------ */
 
 /* COO -> CSR.  Replaces the per-forward index plumbing of PyG's
@@ -266,6 +274,18 @@ int blgnn_linear_x6(const float *x, int64_t ldx, const void *w_packed, float *y,
                     const float *rowvec, const float *rowvec_w, int32_t act,
                     const float *act_param, const float *bn_scale,
                     const float *bn_shift, void *stream);
+
+/* blgnn_linear with the product on the fp16 matrix cores at fp32 accuracy (f16x3: operands range-
+ * normalised by exact powers of two -- X per row inside the kernel, W as a whole when packed -- and
+ * split in two fp16 pieces, three MFMAs per product, see blgnn_gin_layer_h3).  Same call sites as
+ * blgnn_linear (the GMN propagator's f_message / f_node MLPs, model/layers_gmn.py:19-26,39-47, are
+ * the large ones); w_packed = blgnn_pack_weight_h3(W[K,N]).  Needs K % 4 == 0, ldx % 4 == 0 and
+ * 16-byte aligned x / w_packed, otherwise BLGNN_ERR_UNSUPPORTED (use blgnn_linear). */
+int blgnn_linear_h3(const float *x, int64_t ldx, const void *w_packed, float *y,
+                    int64_t ldy, int32_t M, int32_t N, int32_t K, const float *bias,
+                    const float *rowvec, const float *rowvec_w, int32_t act,
+                    const float *act_param, const float *bn_scale, const float *bn_shift,
+                    void *stream);
 
 /* ---- GMN cross-graph attention ------------------------------------------ */
 

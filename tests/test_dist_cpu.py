@@ -107,3 +107,34 @@ def test_two_rank_bilevel_forward_matches_single_process():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def _run_bench(extra_env, *argv):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(conftest.ROOT, "bench.py")] + list(argv), env=env,
+                          capture_output=True, text=True, timeout=240)
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_n_starts_n_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher environment (how the driver calls it) must start two ranks,
+    and the one JSON line must carry the number of ranks that really joined; a failing rank fails the run."""
+    import json
+    r = _run_bench({"BLGNN_BENCH_RENDEZVOUS_ONLY": "1"}, "--gpus", "2", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    r = _run_bench({"BLGNN_BENCH_RENDEZVOUS_ONLY": "1"}, "--gpus", "3", "--config", "3")
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 3
+    assert json.loads(r.stdout.strip().splitlines()[-1])["scaling"] == "strong"
+    r = _run_bench({"BLGNN_BENCH_RENDEZVOUS_ONLY": "1", "BLGNN_BENCH_FAIL_RANK": "1"}, "--gpus", "2")
+    assert r.returncode != 0
+    # a launcher environment that disagrees with --gpus is an error, not a silent 1-GPU line
+    r = _run_bench({"BLGNN_BENCH_RENDEZVOUS_ONLY": "1", "WORLD_SIZE": "1", "RANK": "0"}, "--gpus", "2")
+    assert r.returncode != 0

@@ -204,16 +204,66 @@ def test_engine_graph_replay_and_two_stream_overlap_match_eager(device):
     assert max_err(g.init_x, init_plain) < TOL
     for a, b in zip(refs, plain):
         assert max_err(a, b) < TOL
+    # The sweep's input changes from step to step (written on the sweep's own stream, as a sampler that
+    # refreshes features would), a long blocker delays every interaction-level pass, and EVERY step's
+    # scores are compared with the eager forward of the same inputs: a missing event wait or a wrong
+    # parity buffer (step k+2's sweep overwriting init_x while step k's upper pass still reads it) fails.
+    scales = [1.0 + 0.25 * k for k in range(7)]
+    fresh = ds.pair_gids[rng.choice(len(ds.pair_gids), 96, replace=False)]      # a batch outside the list
+    def which(k):
+        return fresh if k == 5 else k % 3
+    blk_a, blk_b = torch.randn(2048, 2048, device=device), torch.randn(2048, 2048, device=device)
+
+    def live_inputs(engine):
+        """the feature tensors the engine's sweep reads (the fused stack keeps its own tiled copies)"""
+        if engine.fused is None:
+            xs = [lower.merge_data['merge'].x]
+        else:
+            xs = [b.merge_data['merge'].x for b in (engine.fused.small, engine.fused.large) if b is not None]
+        if not hasattr(engine, "_x0"):
+            engine._x0 = [x.clone() for x in xs]
+        return list(zip(xs, engine._x0))
+
+    def set_inputs(engine, scale):
+        for x, x0 in live_inputs(engine):
+            x.copy_(x0 * scale)
+
+    def eager_refs(engine):
+        out = []
+        for k in range(7):
+            set_inputs(engine, scales[k])
+            out.append(engine.eager_step(which(k)).clone())
+        set_inputs(engine, 1.0)
+        torch.cuda.synchronize()
+        return out
+
+    def pipelined(engine):
+        engine.capture()
+        got = []
+        for k in range(7):
+            sl = engine.stream_l if engine.overlap else torch.cuda.current_stream()
+            su = engine.stream_u if engine.overlap else torch.cuda.current_stream()
+            with torch.cuda.stream(sl):
+                set_inputs(engine, scales[k])
+            with torch.cuda.stream(su):
+                for _ in range(4):
+                    torch.mm(blk_a, blk_b)
+            o = engine.step(which(k))
+            with torch.cuda.stream(su):
+                got.append(o.clone())                   # the score buffer is reused two steps later
+        engine.synchronize()
+        set_inputs(engine, 1.0)
+        torch.cuda.synchronize()
+        return got
+
+    refs_f = eager_refs(ref_engine)
     for overlap in (False, True):
-        eng = BiLevelEngine(model, lower, uppers, g, use_graph=True, overlap=overlap, fuse_lower=True)
-        eng.capture()
-        outs = [eng.step(i) for i in range(7)]          # > 2 * parities: buffers are reused
-        eng.synchronize()
-        got = [o.clone() for o in outs[-3:]]
-        for k, o in zip(range(4, 7), got):
-            assert torch.equal(o, refs[k % 3]), (overlap, k)
-    # per-layer kernels, two streams, with the readout riding in the interaction-level graph (default)
+        with BiLevelEngine(model, lower, uppers, g, use_graph=True, overlap=overlap, fuse_lower=True) as eng:
+            for k, o in enumerate(pipelined(eng)):
+                assert torch.equal(o, refs_f[k]), (overlap, k)
+    # per-layer kernels, two streams, with the readout riding in the interaction-level graph
     # and at the tail of the sweep's graph: the same numbers as the eager per-layer forward
+    refs_p = eager_refs(plain_engine)
     for defer, cus in ((True, None), (False, None), (False, 20), (True, 12)):
         # cus: each stream on its own compute units of every XCD (blgnn/streams.py)
         eng = BiLevelEngine(model, lower, uppers, g, use_graph=True, overlap=True, fuse_lower=False,
@@ -221,11 +271,42 @@ def test_engine_graph_replay_and_two_stream_overlap_match_eager(device):
         assert eng.readout_with_upper == defer
         if cus and torch.cuda.get_device_properties(device).multi_processor_count == 256:
             assert eng.lower_cus_per_xcd == cus
+        for k, o in enumerate(pipelined(eng)):
+            assert torch.equal(o, refs_p[k]), (defer, cus, k)
+        eng.close()
+        eng.close()                                     # idempotent
+        with pytest.raises(RuntimeError):
+            eng.step(0)
+
+
+def test_engine_follows_weight_updates_after_capture(device):
+    """captured graphs hold pointers to tensors derived from the weights (packed images, folded BN affines):
+    an in-place weight / running-stat update after capture() must not leave step() replaying stale values"""
+    from blgnn.engine import BiLevelEngine
+    ds = blgnn.make_synthetic(120, 900, seed=22, device=device)
+    flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin",
+                             higher_level_gnn_type="gat", D_lower=128, D_higher=128, device=device)
+    model, data = build(flags, ds, seed=6)
+    lower = blgnn.BatchData(all_molecule_pairs(ds.molecules.gids), ds, is_train=False, ignore_pairs=True)
+    g = ds.interaction_combo_nxgraph
+    g.init_x = torch.zeros((ds.num_graphs(), 5 * 128), device=device)
+    ds.init = True
+    upper = blgnn.BatchData(_pairs(ds, 64), ds, is_train=False)
+    with BiLevelEngine(model, lower, upper, g, use_graph=True, overlap=True) as eng:
         eng.capture()
-        outs = [eng.step(i) for i in range(7)]
+        before = eng.step(0).clone()
         eng.synchronize()
-        for k, o in zip(range(4, 7), [o.clone() for o in outs[-3:]]):
-            assert torch.equal(o, plain[k % 3]), (defer, cus, k)
+        with torch.no_grad():
+            model.layers[0].conv.nn[0].weight.mul_(0.5)
+            model.layers[1].bn.running_var.add_(0.3)
+            model.layers[7].conv.att.mul_(-1.0)
+        after = eng.step(0)
+        eng.synchronize()
+        after = after.clone()
+        ref = eng.eager_step(0)
+        torch.cuda.synchronize()
+        assert torch.equal(after, ref)
+        assert not torch.equal(after, before)
 
 
 @pytest.mark.parametrize("node_aggr", ["avg_pool", "deepsets", "gmn_aggr"])

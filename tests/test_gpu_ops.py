@@ -180,10 +180,12 @@ def test_gin_layer_f16x3_range(device, xs, ws):
     assert float((got.cpu().double() - ref).abs().max() / ref.abs().max()) < TOL
 
 
+@pytest.mark.parametrize("transform", ["f16x3", "bf16x6"])
 @pytest.mark.parametrize("M,N,K", [(32768, 128, 128), (33001, 64, 52), (32800, 100, 36), (11000, 300, 260),
-                                   (32769, 1, 8), (16500, 256, 1024)])
-def test_linear_bf16x6_shapes(device, M, N, K):
-    """bf16x6 split GEMM (large-M path of ops.linear) == fp64 oracle at the fp32 bar"""
+                                   (32769, 1, 8), (16500, 256, 1024), (9000, 1024, 512)])
+def test_linear_split_shapes(device, M, N, K, transform):
+    """split GEMMs on the 16-bit matrix cores (large-M path of ops.linear: fp16 two-piece / bf16 three-piece)
+    == fp64 oracle at the fp32 bar"""
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g)
     w = torch.randn(K, N, generator=g) / max(K, 1) ** 0.5
@@ -191,17 +193,18 @@ def test_linear_bf16x6_shapes(device, M, N, K):
     ref = x.double() @ w.double() + b.double()
     xd, wd = x.to(device), w.to(device)
     assert ops.linear_x6_supported(xd, wd)
-    got = ops.linear(xd, wd, b.to(device), transform="bf16x6")
+    got = ops.linear(xd, wd, b.to(device), transform=transform)
     assert max_err(got, ref) < TOL
     exact = ops.linear(xd, wd, b.to(device), transform="f32")
     assert max_err(exact, ref) < TOL
     # the packed image follows in-place weight updates
     wd.mul_(2.0)
-    assert max_err(ops.linear(xd, wd, b.to(device), transform="bf16x6"), 2.0 * (x.double() @ w.double()) + b.double()) < TOL
+    assert max_err(ops.linear(xd, wd, b.to(device), transform=transform), 2.0 * (x.double() @ w.double()) + b.double()) < TOL
 
 
+@pytest.mark.parametrize("transform", ["f16x3", "bf16x6"])
 @pytest.mark.parametrize("act", ["identity", "relu", "prelu", "sigmoid", "tanh"])
-def test_linear_bf16x6_epilogue(device, act):
+def test_linear_split_epilogue(device, act, transform):
     M, N, K = 33321, 96, 72
     g = torch.Generator().manual_seed(77)
     x, w, b = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g) / 8, torch.randn(N, generator=g)
@@ -212,9 +215,31 @@ def test_linear_bf16x6_epilogue(device, act):
     dv = lambda t: t.to(device)
     wide = torch.zeros(M, N + 8, device=device)
     got = ops.linear(dv(x), dv(w), dv(b), act=act, act_param=dv(slope), bn_scale=dv(scale),
-                     bn_shift=dv(shift), rowvec=dv(rv), rowvec_w=dv(rw), out=wide[:, 4:4 + N], transform="bf16x6")
+                     bn_shift=dv(shift), rowvec=dv(rv), rowvec_w=dv(rw), out=wide[:, 4:4 + N], transform=transform)
     assert max_err(got, ref) < TOL
     assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + N:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("xs,ws", [(1e-6, 1.0), (3e4, 1.0), (1.0, 1e-5), (1.0, 300.0), (1e5, 1e-4)])
+def test_linear_f16x3_range(device, xs, ws):
+    """per-row / per-matrix power-of-two normalisation of the f16x3 GEMM: tiny and huge activations and
+    weights, rows of very different magnitude in one panel, entries spanning six decades inside a row,
+    an all-zero row"""
+    M, N, K = 33000, 192, 256
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(M, K, generator=g) * xs
+    x[::3] *= torch.logspace(-6, 0, K).view(1, -1)
+    x[1::7] *= 1e-4                                          # whole rows far below their neighbours
+    x[5] = 0.0
+    w = torch.randn(K, N, generator=g) / K ** 0.5 * ws
+    ref = x.double() @ w.double()
+    got = ops.linear(x.to(device), w.to(device), transform="f16x3")
+    assert bool(torch.isfinite(got).all())
+    err = (got.cpu().double() - ref).abs()
+    # row-wise bar: every row within 1e-5 of ITS OWN scale (rows differ by 1e4 and more)
+    row_scale = ref.abs().amax(dim=1).clamp_min(1e-30)
+    assert float((err.amax(dim=1) / row_scale)[ref.abs().amax(dim=1) > 0].max()) < TOL
+    assert float(got[5].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("K,N,act", [(52, 64, "relu"), (52, 128, "relu"), (40, 256, "relu"), (64, 64, "identity"),
