@@ -205,8 +205,13 @@ class BiLevelEngine(object):
                           "recv": [torch.empty((self.world * cmax, D), dtype=torch.float32, device=dev)
                                    for _ in range(self.parities)],
                           "rows": torch.as_tensor(src).to(dev), "even": all(c == cmax for c in counts)}
+        # Pinned-memory copies leave events of torch's host allocator on the stream they ran on; those must
+        # never sit on a stream this engine destroys (close()), so the id copies run on an ordinary side
+        # stream and the interaction-level stream waits for an event.
+        self.stream_c = torch.cuda.Stream(device=dev) if self.overlap else None
         self.ev_lower = [None] * self.parities
         self.ev_upper = [None] * self.parities
+        self.ev_ids = [None] * self.parities
         self.step_no = 0
         self._stamp = None
         self._closed = False
@@ -231,16 +236,18 @@ class BiLevelEngine(object):
         return np.ascontiguousarray(self.upper_layers[-1].pair_row_ids(b).T)
 
     def _feed(self, which, parity):
-        """Asynchronous H2D copy of one batch's row ids into the parity's static buffer (on the
-        current stream).  ``which``: list index or [B, 2] graph ids."""
+        """Asynchronous H2D copy of one batch's row ids into the parity's static buffer, on the CURRENT
+        stream.  ``which``: list index or [B, 2] graph ids."""
         if isinstance(which, (int, np.integer)):
             src = self.host_ids[int(which) % self.nb]
         else:
-            if self.ev_upper[parity] is not None:             # the staging buffer's previous copy has run
-                self.ev_upper[parity].synchronize()
+            if self.ev_ids[parity] is not None:               # the staging buffer's previous copy has run
+                self.ev_ids[parity].synchronize()
             src = self.stage_ids[parity]
             src.copy_(torch.from_numpy(self.rows_of(which)))
         self.ids_dev[parity].copy_(src, non_blocking=True)
+        self.ev_ids[parity] = torch.cuda.Event()
+        self.ev_ids[parity].record(torch.cuda.current_stream())
 
     # ---- the three pieces of one forward -------------------------------------------------
     def lower(self, parity=0, readout=True):
@@ -354,8 +361,14 @@ class BiLevelEngine(object):
             self.exchange(self.pooled[p], p)
             self.ev_lower[p] = torch.cuda.Event()
             self.ev_lower[p].record(self.stream_l)
+        with torch.cuda.stream(self.stream_c):
+            if self.ev_upper[p] is not None:                   # ids_dev[p] is free once step k-2 scored
+                self.stream_c.wait_event(self.ev_upper[p])
+            else:
+                self.stream_c.wait_stream(cur)
+            self._feed(which, p)
         with torch.cuda.stream(self.stream_u):
-            self._feed(which, p)                               # in order behind step k-2's upper graph
+            self.stream_u.wait_event(self.ev_ids[p])
             self.stream_u.wait_event(self.ev_lower[p])
             self.g_upper[p].replay()
             self.ev_upper[p] = torch.cuda.Event()
@@ -367,6 +380,7 @@ class BiLevelEngine(object):
             cur = torch.cuda.current_stream()
             cur.wait_stream(self.stream_l)
             cur.wait_stream(self.stream_u)
+            cur.wait_stream(self.stream_c)
         torch.cuda.synchronize()
 
     def close(self):
@@ -380,7 +394,8 @@ class BiLevelEngine(object):
         self.g_upper = [None] * self.parities
         self.ev_lower = [None] * self.parities
         self.ev_upper = [None] * self.parities
-        self.stream_l = self.stream_u = None
+        self.ev_ids = [None] * self.parities
+        self.stream_l = self.stream_u = self.stream_c = None
         if self._masked is not None:
             self._masked.close()
             self._masked = None

@@ -15,7 +15,7 @@ from .config import FLAGS
 
 __all__ = [
     "CSR", "csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear",
-    "gat_conv", "gcn_conv", "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum",
+    "gat_conv", "gcn_conv", "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum", "row_absmax",
     "row_degree", "link_pred_head", "pack_weight_x6", "pack_weight_h3", "gin_layer_h3", "gin_layer_h3_supported", "linear_x6_supported", "gin_layer_x6", "gin_layer_x6_supported", "gin_stack", "molecule_tiles", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
     "require_device",
 ]
@@ -281,11 +281,21 @@ def linear_x6_supported(x, w_kn):
             and tiles >= LINEAR_X6_MIN_TILES)
 
 
+def row_absmax(x, out=None):
+    """max_k |x[m, k]| per row (the normalisation input of the f16x3 GEMM)."""
+    xp, ldx = _mat(x, "x")
+    if out is None:
+        out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    call("blgnn_row_absmax", xp, ldx, x.shape[0], x.shape[1], _vec(out, "out", optional=False), _stream())
+    return out
+
+
 def linear(x, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn_shift=None,
-           rowvec=None, rowvec_w=None, out=None, transform=None):
+           rowvec=None, rowvec_w=None, out=None, transform=None, row_amax=None):
     """epi(x @ w_kn + bias [+ rowvec (x) rowvec_w]); w_kn is [K, N] row-major.
     ``transform``: "f16x3" / "bf16x6" (16-bit matrix cores, fp32-equivalent, large M only), "f32"
-    (exact-f32 MFMA) or None = FLAGS.feature_transform."""
+    (exact-f32 MFMA) or None = FLAGS.feature_transform.  ``row_amax`` [M]: row magnitudes of ``x`` when
+    the caller already has them (f16x3 only; computed by one extra pass over x otherwise)."""
     xp, ldx = _mat(x, "x")
     wp, ldw = _mat(w_kn, "w")
     M, K = x.shape
@@ -299,8 +309,15 @@ def linear(x, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn
     if transform in ("bf16x6", "f16x3") and K > 0 and N > 0 and linear_x6_supported(x, w_kn):
         # large-M GEMMs on the 16-bit matrix cores at fp32 accuracy: fp16 two-piece split (three MFMAs per
         # product) or bf16 three-piece split (six)
-        name, kind = ("blgnn_linear_h3", "h3") if transform == "f16x3" else ("blgnn_linear_x6", "x6")
-        call(name, xp, ldx, _packed_weight(w_kn, kind).data_ptr(), yp, ldy, M, N, K, _vec(bias, "bias"),
+        if transform == "f16x3":
+            if row_amax is None:
+                row_amax = row_absmax(x)
+            call("blgnn_linear_h3", xp, ldx, _vec(row_amax, "row_amax", optional=False),
+                 _packed_weight(w_kn, "h3").data_ptr(), yp, ldy, M, N, K, _vec(bias, "bias"),
+                 _vec(rowvec, "rowvec"), _vec(rowvec_w, "rowvec_w"), _act(act), _vec(act_param, "act_param"),
+                 _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), _stream())
+            return y
+        call("blgnn_linear_x6", xp, ldx, _packed_weight(w_kn, "x6").data_ptr(), yp, ldy, M, N, K, _vec(bias, "bias"),
              _vec(rowvec, "rowvec"), _vec(rowvec_w, "rowvec_w"), _act(act), _vec(act_param, "act_param"),
              _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), _stream())
         return y

@@ -30,7 +30,7 @@ __device__ __forceinline__ float act_c(float v, float slope) {
 // One wave's TM x TN accumulator tiles -> y, 32 rows at a time through its private LDS tile.
 // ``rs`` (LDS, outside the staging tiles; indexed by row - row0) and ``cs`` undo the power-of-two
 // operand scaling of the f16x3 kernels: acc * rs[row] * cs before the bias.
-template <int ACT, int TM, int TN, int WN>
+template <int ACT, int TM, int TN, int WN, bool SYNC = true>
 __device__ __forceinline__ void store_out(const LinearArgs &A, const f32x16 (&acc)[TM][TN], float *smem,
                                           int row0, int col0, int wid, int lane,
                                           const float *rs = nullptr, float cs = 1.f) {
@@ -50,7 +50,7 @@ __device__ __forceinline__ void store_out(const LinearArgs &A, const f32x16 (&ac
         shift[j] = (in && A.epi.bn_scale && A.epi.bn_shift) ? A.epi.bn_shift[n] : 0.f;
         rw[j] = (in && A.rowvec_w) ? A.rowvec_w[n] : 0.f;
     }
-    __syncthreads();                                     // every wave is done reading As / Bs
+    if (SYNC) __syncthreads();                           // every wave is done reading As / Bs
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll

@@ -7,18 +7,24 @@
 // These are the GEMMs of the GMN propagator (model/layers_gmn.py:19-26,39-47: f_message, f_node) and
 // every other nn.Linear / x @ W of the path once M is large.
 //
-// Range normalisation of X: a workgroup first sweeps its 128 rows once (the panel then sits in the
-// XCD's L2 for the K loop and for the sibling column blocks) and scales every row by the power of two
-// that moves its largest magnitude into [2^14, 2^15); the inverse goes onto the fp32 accumulators in
-// the epilogue together with the weight matrix's.
+// Range normalisation of X: every row is scaled by the power of two that moves its largest magnitude
+// (row_amax[m], from blgnn_row_absmax or from the kernel that produced X) into [2^14, 2^15); the
+// inverse goes onto the fp32 accumulators in the epilogue together with the weight matrix's.
 //
-// Structure: 256 threads = 2 x 2 wavefronts, block tile 128 x 128, wave tile 64 x 64, K step 32
-// (two MFMA k steps per barrier).  X tile: global fp32 -> registers (requested two K steps ahead) ->
-// scale -> split -> two fp16 images [piece][m][32 k] in LDS.  W tile: the packed pieces are copied as
-// they are into [piece][n][32 k].  Rows are 64 B with the 16-byte chunk index XORed by (row >> 2) & 3:
-// the 16 lanes a ds_read_b128 serves together then cover all 16 chunk slots of the 256-byte bank row.
-// Workgroups that share an X row panel run on one XCD (their ids are remapped so that an XCD owns a
-// contiguous range of tiles), so the panel leaves HBM once.
+// Structure: one 512-thread workgroup per CU, block tile 128 x 128, K step 64, ROLE SPLIT:
+//   waves 0-3 (one per SIMD) only read operand fragments from LDS and issue MFMAs (2 x 2 tiles of
+//             32 x 32 each, 48 MFMAs per K step) and own the epilogue;
+//   waves 4-7 (the second wave of each SIMD) own all global traffic and all vector work: X tile
+//             fp32 -> registers (requested three K steps ahead) -> scale -> split -> two fp16 images in
+//             LDS; packed W pieces copied as they are.
+// One barrier per K step, two LDS buffers of 64 KB.  A measured knock-out of the single-role version
+// (four waves doing everything, two workgroups per CU) showed its phases adding up -- row sweep 2.3 ms,
+// LDS / conversion 2.0 ms, MFMA 1.2 ms, loads 0.8 ms on 462 k x 1024 x 1024 -- instead of overlapping:
+// with one wave per SIMD and workgroup, nothing runs under a wave's MFMAs but its own next instruction.
+// LDS rows are 128 B (64 fp16) with the 16-byte chunk index XORed by (row >> 1) & 7: the 16 lanes a
+// ds_read_b128 serves together then cover all 16 chunk slots of the 256-byte bank row.
+// Workgroups that share an X row panel run on one XCD (ids remapped so an XCD owns a contiguous run
+// of tiles).
 #include "linear_common.hpp"
 #include "h3_common.hpp"
 
@@ -27,22 +33,45 @@ namespace blgnn {
 struct LinearH3Args {
     LinearArgs base;             // x, ldx, y, ldy, M, N, K, rowvec, rowvec_w, epi (w / ldw unused)
     const _Float16 *wp;          // header (inverse scale) + pieces [2][Kp/8][N][8]
+    const float *row_amax;       // [M] largest magnitude of every X row
     int32_t Kp;                  // K rounded up to 32
 };
 
-constexpr int HBK = 32;                   // K step
-constexpr int HROW = HBK * 2;             // LDS row: 32 fp16 = 64 B = four 16-byte chunks, XOR swizzled
+constexpr int HBK = 64;                   // K step
+constexpr int HROW = HBK * 2;             // LDS row: 64 fp16 = 128 B = eight 16-byte chunks, XOR swizzled
 constexpr int H3_BM = 128, H3_BN = 128;
-constexpr int H3_PIECE = H3_BM * HROW;    // bytes of one piece image (BM == BN)
-constexpr int H3_BUF = 4 * H3_PIECE;      // 2 X pieces + 2 W pieces
-constexpr int H3_STAGE = 4 * 32 * (64 + 4) * 4;          // store_out's per-wave staging tiles
-constexpr int H3_MAIN = 2 * H3_BUF > H3_STAGE ? 2 * H3_BUF : H3_STAGE;
+constexpr int H3_PIECE = H3_BM * HROW;    // bytes of one piece image (BM == BN): 16 KB
+constexpr int H3_BUF = 4 * H3_PIECE;      // 2 X pieces + 2 W pieces: 64 KB
+constexpr int H3_MAIN = 2 * H3_BUF;       // (the epilogue's staging tiles, 34 KB, reuse it)
 constexpr int H3_LDS = H3_MAIN + H3_BM * 4;              // + inverse row scales
 
-__device__ __forceinline__ int h3_off(int row, int chunk) { return row * HROW + ((chunk ^ ((row >> 2) & 3)) << 4); }
+__device__ __forceinline__ int h3_off(int row, int chunk) { return row * HROW + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// ---- row maxima: out[m] = max_k |x[m, k]|, one wave per row -------------------------------------------------
+__global__ void __launch_bounds__(256) k_row_absmax(const float *__restrict__ x, int64_t ldx, int M, int K,
+                                                    float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float *p = x + (int64_t)row * ldx;
+    float m = 0.f;
+    if ((ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+        const float4 *p4 = reinterpret_cast<const float4 *>(p);
+        const int k4 = K >> 2;
+        for (int c = lane; c < k4; c += 64) {
+            const float4 v = p4[c];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        for (int k = (k4 << 2) + lane; k < K; k += 64) m = fmaxf(m, fabsf(p[k]));
+    } else {
+        for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(p[k]));
+    }
+    m = group_max(m, WAVE);
+    if (lane == 0) out[row] = m;
+}
 
 template <int ACT>
-__global__ void __launch_bounds__(256, 2) k_linear_h3(const LinearH3Args P) {
+__global__ void __launch_bounds__(512, 2) k_linear_h3(const LinearH3Args P) {
     constexpr int BM = H3_BM, BN = H3_BN, WM = 64, WN = 64, TM = 2, TN = 2, PIECE = H3_PIECE;
     extern __shared__ float4 h3_smem[];
     char *smem_raw = reinterpret_cast<char *>(h3_smem);
@@ -50,8 +79,6 @@ __global__ void __launch_bounds__(256, 2) k_linear_h3(const LinearH3Args P) {
     const LinearArgs &A = P.base;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int fi = lane & 31, fh = lane >> 5;
-    const int wm0 = (wid >> 1) * WM, wn0 = (wid & 1) * WN;
     // tile <- block id: blocks b, b + 8, ... share an XCD; give each XCD a contiguous run of tiles
     // (row-panel major), so the column blocks of one row panel read it from the same L2
     const int nb = (A.N + BN - 1) / BN;
@@ -61,41 +88,89 @@ __global__ void __launch_bounds__(256, 2) k_linear_h3(const LinearH3Args P) {
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
     const int m0 = (tile / nb) * BM, n0 = (tile % nb) * BN;
+    const int KT = (P.Kp + HBK - 1) / HBK;
 
-    const int a_kq = tid & 7, a_row = tid >> 3;          // 8 threads x 16 B per X row of a K step, 32 rows per pass
-    const float4 *__restrict__ X4 = reinterpret_cast<const float4 *>(A.x);
-    const int64_t ldx4 = A.ldx >> 2;
-    const int64_t wpiece = (int64_t)(P.Kp / 8) * A.N;    // 16-byte words per packed piece
-    const f16x8 *__restrict__ W8 = reinterpret_cast<const f16x8 *>(P.wp + HHDR);
-    const float winv = *reinterpret_cast<const float *>(P.wp);
-
-    // ---- row maxima of the X panel -> power-of-two scales ------------------------------------------------
-    float rscale[4];
-    {
-        float am[4] = {0.f, 0.f, 0.f, 0.f};
-        const int k4n = A.K >> 2;
-#pragma unroll 4
-        for (int c = a_kq; c < k4n; c += 8)
+    if (wid >= 4) {
+        // =================================== feeder waves ===================================
+        const int ptid = tid - 256;
+        const int a_kq = ptid & 15, a_row = ptid >> 4;        // 16 threads x 16 B per X row of a K step, 16 rows per pass
+        const int w_kb = ptid >> 7, w_n = ptid & 127;         // W word (piece i >> 2, k block w_kb + 2 (i & 3), column w_n)
+        const float4 *__restrict__ X4 = reinterpret_cast<const float4 *>(A.x);
+        const int64_t ldx4 = A.ldx >> 2;
+        const int64_t wpiece = (int64_t)(P.Kp / 8) * A.N;     // 16-byte words per packed piece
+        const f16x8 *__restrict__ W8 = reinterpret_cast<const f16x8 *>(P.wp + HHDR);
+        float rscale[8];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int m = m0 + a_row + 32 * p;
-                if (m < A.M) {
-                    const float4 v = X4[(int64_t)m * ldx4 + c];
-                    am[p] = fmaxf(fmaxf(am[p], fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-                }
+        for (int p = 0; p < 8; ++p) {
+            const int m = m0 + a_row + 16 * p;
+            float inv;
+            pow2_scale(m < A.M ? P.row_amax[m] : 0.f, rscale[p], inv);
+            if (a_kq == 0) rinv[a_row + 16 * p] = inv;
+        }
+        auto load_tile = [&](float4 (&ra)[8], f16x8 (&rb)[8], int kt) {
+            const int k0 = kt * HBK;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int m = m0 + a_row + 16 * p, k = k0 + 4 * a_kq;
+                ra[p] = (m < A.M && k < A.K) ? X4[(int64_t)m * ldx4 + (k >> 2)] : f4_zero();
             }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            float a = am[p];
-            a = fmaxf(a, __shfl_xor(a, 1, WAVE));
-            a = fmaxf(a, __shfl_xor(a, 2, WAVE));
-            a = fmaxf(a, __shfl_xor(a, 4, WAVE));
-            float inv;
-            pow2_scale(a, rscale[p], inv);
-            if (a_kq == 0) rinv[a_row + 32 * p] = inv;
+            for (int i = 0; i < 8; ++i) {
+                const int q = i >> 2, kb = (k0 >> 3) + w_kb + 2 * (i & 3), n = n0 + w_n;
+                f16x8 z;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
+                rb[i] = (n < A.N && kb < (P.Kp >> 3)) ? W8[q * wpiece + (int64_t)kb * A.N + n] : z;
+            }
+        };
+        auto store_tile = [&](const float4 (&ra)[8], const f16x8 (&rb)[8], char *buf) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const float s = rscale[p];
+                const Split2 s0 = split2(ra[p].x * s), s1 = split2(ra[p].y * s), s2 = split2(ra[p].z * s),
+                             s3 = split2(ra[p].w * s);
+                f16x4 h1 = {s0.h1, s1.h1, s2.h1, s3.h1}, h2 = {s0.h2, s1.h2, s2.h2, s3.h2};
+                char *dst = buf + h3_off(a_row + 16 * p, a_kq >> 1) + (a_kq & 1) * 8;
+                *reinterpret_cast<f16x4 *>(dst) = h1;
+                *reinterpret_cast<f16x4 *>(dst + PIECE) = h2;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<f16x8 *>(buf + (2 + (i >> 2)) * PIECE + h3_off(w_n, w_kb + 2 * (i & 3))) = rb[i];
+        };
+        // register ring of two K steps; loads past the end re-read the last step (never stored)
+        float4 xa0[8], xa1[8];
+        f16x8 wb0[8], wb1[8];
+        const int last = KT - 1;
+        load_tile(xa0, wb0, 0);
+        load_tile(xa1, wb1, 1 < last ? 1 : last);
+        store_tile(xa0, wb0, smem_raw);                       // step 0 -> buffer 0
+        load_tile(xa0, wb0, 2 < last ? 2 : last);
+        lds_barrier();
+        // step kt: the MFMA waves read buffer kt & 1; this half writes step kt + 1 into the other buffer
+        // (registers (kt + 1) & 1) and re-requests those registers for step kt + 3
+        for (int kt = 0; kt < KT; kt += 2) {
+            if (kt + 1 < KT) {
+                store_tile(xa1, wb1, smem_raw + H3_BUF);
+                load_tile(xa1, wb1, kt + 3 < last ? kt + 3 : last);
+            }
+            lds_barrier();
+            if (kt + 1 < KT) {
+                if (kt + 2 < KT) {
+                    store_tile(xa0, wb0, smem_raw);
+                    load_tile(xa0, wb0, kt + 4 < last ? kt + 4 : last);
+                }
+                lds_barrier();
+            }
         }
+        lds_barrier();                                        // pairs with the barrier in front of the epilogue
+        return;
     }
 
+    // =================================== MFMA waves ===================================
+    const int fi = lane & 31, fh = lane >> 5;
+    const int wm0 = (wid >> 1) * WM, wn0 = (wid & 1) * WN;
+    const float winv = *reinterpret_cast<const float *>(P.wp);
     f32x16 acc0[TM][TN], acc1[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -103,55 +178,14 @@ __global__ void __launch_bounds__(256, 2) k_linear_h3(const LinearH3Args P) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
-
-    // staging registers: X tile 128 x 32 fp32 = 4 float4 per thread; W pieces 2 x 4 x 128 words of 16 B = 4
-    float4 ra[4];
-    f16x8 rb[4];
-    const int w_kb = tid >> 7, w_n = tid & 127;           // word (piece q, k block kb + 2 h, column n)
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int m = m0 + a_row + 32 * p, k = k0 + 4 * a_kq;
-            ra[p] = (m < A.M && k < A.K) ? X4[(int64_t)m * ldx4 + (k >> 2)] : f4_zero();
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = i >> 1, kb = w_kb + 2 * (i & 1), n = n0 + w_n;
-            f16x8 z;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
-            rb[i] = n < A.N ? W8[q * wpiece + (int64_t)(k0 / 8 + kb) * A.N + n] : z;
-        }
-    };
-    auto store_tile = [&](char *buf) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const float s = rscale[p];
-            const Split2 s0 = split2(ra[p].x * s), s1 = split2(ra[p].y * s), s2 = split2(ra[p].z * s),
-                         s3 = split2(ra[p].w * s);
-            f16x4 h1 = {s0.h1, s1.h1, s2.h1, s3.h1}, h2 = {s0.h2, s1.h2, s2.h2, s3.h2};
-            char *dst = buf + h3_off(a_row + 32 * p, a_kq >> 1) + (a_kq & 1) * 8;
-            *reinterpret_cast<f16x4 *>(dst) = h1;
-            *reinterpret_cast<f16x4 *>(dst + PIECE) = h2;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<f16x8 *>(buf + (2 + (i >> 1)) * PIECE + h3_off(w_n, w_kb + 2 * (i & 1))) = rb[i];
-    };
-
-    const int KT = P.Kp / HBK;
-    load_tile(0);
-    store_tile(smem_raw);
-    if (KT > 1) load_tile(HBK);
-    lds_barrier();
-    // lane (row fi, k half fh) of a 32-row fragment tile; 32-row offsets keep (row >> 2) & 3 == (fi >> 2) & 3
-    const int sw = (fi >> 2) & 3;
+    // lane (row fi, k half fh) of a 32-row fragment tile; 32-row offsets keep (row >> 1) & 7 == (fi >> 1) & 7
+    const int sw = (fi >> 1) & 7;
     const int arow = (wm0 + fi) * HROW, brow = 2 * PIECE + (wn0 + fi) * HROW;
+    lds_barrier();                                            // buffer 0 is complete
     for (int kt = 0; kt < KT; ++kt) {
         const char *cur = smem_raw + (kt & 1) * H3_BUF;
-        char *nxt = smem_raw + ((kt & 1) ^ 1) * H3_BUF;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < 4; ++s) {
             const int coff = ((2 * s + fh) ^ sw) << 4;
             f16x8 a[TM][2], b[TN][2];
 #pragma unroll
@@ -169,22 +203,19 @@ __global__ void __launch_bounds__(256, 2) k_linear_h3(const LinearH3Args P) {
         ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][QA], b[j][QB], ACC[i][j], 0, 0, 0);
             H3_TERM(acc0, 0, 0)
             H3_TERM(acc1, 0, 1)
-            if (s == 0) {
-                if (kt + 1 < KT) store_tile(nxt);            // registers hold step kt+1
-                if (kt + 2 < KT) load_tile((kt + 2) * HBK);
-            }
             H3_TERM(acc1, 1, 0)
 #undef H3_TERM
         }
-        lds_barrier();       // buffer kt&1 fully read (it is overwritten in step kt+1), buffer (kt+1)&1 complete
+        lds_barrier();       // buffer kt & 1 fully read (rewritten during step kt + 1), buffer (kt + 1) & 1 complete
     }
+    lds_barrier();                                            // every wave is done with the operand buffers
 
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc0[i][j] += acc1[i][j];
-    store_out<ACT, TM, TN, WN>(A, acc0, reinterpret_cast<float *>(smem_raw), m0 + wm0, n0 + wn0, wid, lane,
-                               rinv + wm0, winv);
+    store_out<ACT, TM, TN, WN, false>(A, acc0, reinterpret_cast<float *>(smem_raw), m0 + wm0, n0 + wn0, wid, lane,
+                                      rinv + wm0, winv);
 }
 
 template <int ACT>
@@ -197,7 +228,7 @@ static int launch_linear_h3(const LinearH3Args &P, hipStream_t s) {
         declared = true;
     }
     const int64_t blocks = (int64_t)((P.base.M + H3_BM - 1) / H3_BM) * ((P.base.N + H3_BN - 1) / H3_BN);
-    hipLaunchKernelGGL(k_linear_h3<ACT>, dim3((unsigned)blocks), dim3(256), H3_LDS, s, P);
+    hipLaunchKernelGGL(k_linear_h3<ACT>, dim3((unsigned)blocks), dim3(512), H3_LDS, s, P);
     return launch_status("linear_h3");
 }
 
@@ -205,13 +236,21 @@ static int launch_linear_h3(const LinearH3Args &P, hipStream_t s) {
 
 using namespace blgnn;
 
-extern "C" int blgnn_linear_h3(const float *x, int64_t ldx, const void *w_packed, float *y, int64_t ldy,
-                               int32_t M, int32_t N, int32_t K, const float *bias, const float *rowvec,
+extern "C" int blgnn_row_absmax(const float *x, int64_t ldx, int32_t M, int32_t K, float *out, void *stream) {
+    BLGNN_CHECK_ARG(M >= 0 && K > 0, "row_absmax: bad sizes");
+    if (M == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(x && out && ldx >= K, "row_absmax: bad args");
+    hipLaunchKernelGGL(k_row_absmax, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, M, K, out);
+    return launch_status("row_absmax");
+}
+
+extern "C" int blgnn_linear_h3(const float *x, int64_t ldx, const float *row_amax, const void *w_packed, float *y,
+                               int64_t ldy, int32_t M, int32_t N, int32_t K, const float *bias, const float *rowvec,
                                const float *rowvec_w, int32_t act, const float *act_param,
                                const float *bn_scale, const float *bn_shift, void *stream) {
     BLGNN_CHECK_ARG(M >= 0 && N >= 0 && K > 0, "linear_h3: bad sizes");
     if (M == 0 || N == 0) return BLGNN_OK;
-    BLGNN_CHECK_ARG(x && w_packed && y, "linear_h3: null pointer");
+    BLGNN_CHECK_ARG(x && row_amax && w_packed && y, "linear_h3: null pointer");
     BLGNN_CHECK_ARG(ldx >= K && ldy >= N, "linear_h3: leading dimension too small");
     BLGNN_CHECK_ARG(act >= 0 && act <= BLGNN_ACT_TANH, "linear_h3: bad activation id");
     BLGNN_CHECK_ARG((rowvec == nullptr) == (rowvec_w == nullptr), "linear_h3: rowvec and rowvec_w go together");
@@ -226,6 +265,7 @@ extern "C" int blgnn_linear_h3(const float *x, int64_t ldx, const void *w_packed
     A.epi = Epilogue{bias, act_param, bn_scale, bn_shift, act};
     A.vec_a = 1; A.vec_b = 0;
     P.wp = reinterpret_cast<const _Float16 *>(w_packed);
+    P.row_amax = row_amax;
     P.Kp = (K + 31) / 32 * 32;
     hipStream_t s = (hipStream_t)stream;
     switch (act) {

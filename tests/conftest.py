@@ -19,3 +19,39 @@ def device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return "cuda:0"
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Write the measured parity errors of this session (tests/helpers.py:ERROR_LOG) where the GPU box's
+    output directory is merged back from: gpurun_out/parity_errors.json."""
+    try:
+        import json
+        import helpers
+        if not helpers.ERROR_LOG:
+            return
+        summary = {}
+        for test, rows in helpers.ERROR_LOG.items():
+            summary[test] = {"comparisons": len(rows), "max_abs": max(r["abs"] for r in rows),
+                             "max_scaled": max(r["scaled"] for r in rows),
+                             "max_ref_magnitude": max(r["ref_max"] for r in rows)}
+        out = {"bar": helpers.TOL, "worst_abs": max(v["max_abs"] for v in summary.values()),
+               "worst_scaled": max(v["max_scaled"] for v in summary.values()), "tests": summary}
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_errors.json"), "w") as f:
+            json.dump(out, f, indent=1, sort_keys=True)
+    except Exception:                                        # reporting must never fail a run
+        pass
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    try:
+        import helpers
+        rows = [r for v in helpers.ERROR_LOG.values() for r in v]
+        if rows:
+            terminalreporter.write_line(
+                "parity: %d comparisons, worst abs %.3e, worst scaled %.3e (bar %.0e); per test -> "
+                "gpurun_out/parity_errors.json" % (len(rows), max(r["abs"] for r in rows),
+                                                    max(r["scaled"] for r in rows), helpers.TOL))
+    except Exception:
+        pass
