@@ -135,24 +135,33 @@ class MLP(nn.Module):
         return self._cache.get(("fold", i), fold, lin.weight, lin.bias, bn.weight, bn.bias,
                                bn.running_mean, bn.running_var)
 
-    def forward(self, x, out=None, first_rowvec=None, final_act="identity"):
+    def forward(self, x, out=None, first_rowvec=None, final_act="identity", row_amax=None):
         """``out``: optional destination for the last layer (may be a column slice).
         ``final_act``: activation fused after the last Linear (the caller's sigmoid).
         ``first_rowvec`` = (rowvec, rowvec_w): rank-1 term added inside the first
-        layer's GEMM (used by the restructured GMN message)."""
+        layer's GEMM (used by the restructured GMN message).  ``row_amax``: row magnitudes
+        of ``x`` if the caller has them; between layers they come out of the producing GEMM's
+        epilogue (f16x3 path), so only the first layer may need a pass over its input."""
         act = act_name(self.activation)
         last = len(self.layers) - 1
+        amax = row_amax
         for i, lin in enumerate(self.layers):
             kw = {}
             if i == 0 and first_rowvec is not None:
                 kw["rowvec"], kw["rowvec_w"] = first_rowvec
             if i == last:
-                x = ops.linear(x, self.weight_kn(i), lin.bias, act=final_act, out=out, **kw)
+                w, b, a = self.weight_kn(i), lin.bias, final_act
+                kw["out"] = out
             elif self.bn:
                 w, b = self._folded(i)
-                x = ops.linear(x, w, b, act=act, **kw)
+                a = act
             else:
-                x = ops.linear(x, self.weight_kn(i), lin.bias, act=act, **kw)
+                w, b, a = self.weight_kn(i), lin.bias, act
+            nxt = None
+            if i < last and ops.linear_writes_amax(x, w):
+                nxt = torch.zeros(x.shape[0], dtype=torch.float32, device=x.device)
+            x = ops.linear(x, w, b, act=a, row_amax=amax, amax_out=nxt, **kw)
+            amax = nxt
         return x
 
 

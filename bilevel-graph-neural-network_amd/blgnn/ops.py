@@ -15,7 +15,7 @@ from .config import FLAGS
 
 __all__ = [
     "CSR", "csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear",
-    "gat_conv", "gcn_conv", "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum", "row_absmax",
+    "gat_conv", "gcn_conv", "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum", "row_absmax", "linear_writes_amax", "linear_h3_preferred",
     "row_degree", "link_pred_head", "pack_weight_x6", "pack_weight_h3", "gin_layer_h3", "gin_layer_h3_supported", "linear_x6_supported", "gin_layer_x6", "gin_layer_x6_supported", "gin_stack", "molecule_tiles", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
     "require_device",
 ]
@@ -275,6 +275,22 @@ def _packed_weight(w_kn, kind="x6"):
     return packed
 
 
+def linear_writes_amax(x, w_kn, transform=None):
+    """True when ``linear(x, w_kn, ..., transform=transform, amax_out=...)`` will fill ``amax_out``
+    (the f16x3 kernel runs)."""
+    if transform is not None:
+        return transform == "f16x3" and x.shape[1] > 0 and w_kn.shape[1] > 0 and linear_x6_supported(x, w_kn)
+    return getattr(FLAGS, "feature_transform", "bf16x6") == "f16x3" and linear_h3_preferred(x, w_kn)
+
+
+def linear_h3_preferred(x, w_kn):
+    """Shapes where the f16x3 GEMM (one 512-thread workgroup per CU, K step 64) beats the bf16x6 one
+    (measured on MI355X, 462 k rows: K x N = 256 x 1024, 512 x 512, 1024 x 256, 1024 x 1024: 1.1-1.35x
+    faster; 256 x 256 and below: its per-tile prologue / epilogue is not amortised, bf16x6 wins)."""
+    return (x.shape[1] > 0 and w_kn.shape[1] > 0 and linear_x6_supported(x, w_kn)
+            and x.shape[1] * w_kn.shape[1] >= 256 * 1024 and x.shape[0] >= 32768)
+
+
 def linear_x6_supported(x, w_kn):
     tiles = ((x.shape[0] + 127) // 128) * ((w_kn.shape[1] + 127) // 128)
     return (x.shape[1] % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
@@ -291,11 +307,13 @@ def row_absmax(x, out=None):
 
 
 def linear(x, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn_shift=None,
-           rowvec=None, rowvec_w=None, out=None, transform=None, row_amax=None):
+           rowvec=None, rowvec_w=None, out=None, transform=None, row_amax=None, amax_out=None):
     """epi(x @ w_kn + bias [+ rowvec (x) rowvec_w]); w_kn is [K, N] row-major.
     ``transform``: "f16x3" / "bf16x6" (16-bit matrix cores, fp32-equivalent, large M only), "f32"
     (exact-f32 MFMA) or None = FLAGS.feature_transform.  ``row_amax`` [M]: row magnitudes of ``x`` when
-    the caller already has them (f16x3 only; computed by one extra pass over x otherwise)."""
+    the caller already has them (f16x3 only; computed by one extra pass over x otherwise).  ``amax_out``
+    [M], zero-initialised: receives the row magnitudes of the RESULT when the f16x3 kernel runs (the
+    ``row_amax`` of a following GEMM on it); callers must check ``linear_writes_amax`` first."""
     xp, ldx = _mat(x, "x")
     wp, ldw = _mat(w_kn, "w")
     M, K = x.shape
@@ -304,16 +322,18 @@ def linear(x, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn
     N = w_kn.shape[1]
     y = _out(out, M, N, x)
     yp, ldy = _mat(y, "out")
+    explicit = transform is not None                      # an explicit "f16x3" forces that kernel (tests, benches)
     if transform is None:
         transform = getattr(FLAGS, "feature_transform", "bf16x6")
     if transform in ("bf16x6", "f16x3") and K > 0 and N > 0 and linear_x6_supported(x, w_kn):
         # large-M GEMMs on the 16-bit matrix cores at fp32 accuracy: fp16 two-piece split (three MFMAs per
         # product) or bf16 three-piece split (six)
-        if transform == "f16x3":
+        if transform == "f16x3" and (explicit or linear_h3_preferred(x, w_kn)):
             if row_amax is None:
                 row_amax = row_absmax(x)
             call("blgnn_linear_h3", xp, ldx, _vec(row_amax, "row_amax", optional=False),
-                 _packed_weight(w_kn, "h3").data_ptr(), yp, ldy, M, N, K, _vec(bias, "bias"),
+                 _packed_weight(w_kn, "h3").data_ptr(), yp, ldy, _vec(amax_out, "amax_out"), M, N, K,
+                 _vec(bias, "bias"),
                  _vec(rowvec, "rowvec"), _vec(rowvec_w, "rowvec_w"), _act(act), _vec(act_param, "act_param"),
                  _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), _stream())
             return y

@@ -11,6 +11,7 @@ namespace blgnn {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4h __attribute__((ext_vector_type(4)));
 
 constexpr int HHDR = 8;          // packed image header, in fp16 elements (16 bytes): float inv_scale

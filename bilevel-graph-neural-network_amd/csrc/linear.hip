@@ -337,7 +337,7 @@ extern "C" int blgnn_linear(const float *x, int64_t ldx, const float *w, int64_t
     A.M = M; A.N = N; A.K = K; A.rowvec = rowvec; A.rowvec_w = rowvec_w;
     A.epi = Epilogue{bias, act_param, bn_scale, bn_shift, act};
     A.vec_a = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(x);
-    A.vec_b = (N % 4 == 0) && (ldw % 4 == 0) && aligned16(w);
+    A.vec_b = (N % 4 == 0) && (ldw % 4 == 0) && aligned16(w); A.amax_out = nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (N <= 32) {
         if (M >= 32768) launch_linear<256, 32, 64, 32>(A, s);

@@ -14,9 +14,9 @@
 // Structure: one 512-thread workgroup per CU, block tile 128 x 128, K step 64, ROLE SPLIT:
 //   waves 0-3 (one per SIMD) only read operand fragments from LDS and issue MFMAs (2 x 2 tiles of
 //             32 x 32 each, 48 MFMAs per K step) and own the epilogue;
-//   waves 4-7 (the second wave of each SIMD) own all global traffic and all vector work: X tile
-//             fp32 -> registers (requested three K steps ahead) -> scale -> split -> two fp16 images in
-//             LDS; packed W pieces copied as they are.
+//             They also copy the packed W pieces of the next step global -> registers -> LDS.
+//   waves 4-7 (the second wave of each SIMD) own the X operand and all vector work: X tile fp32 ->
+//             registers (requested three K steps ahead) -> scale -> split -> two fp16 images in LDS.
 // One barrier per K step, two LDS buffers of 64 KB.  A measured knock-out of the single-role version
 // (four waves doing everything, two workgroups per CU) showed its phases adding up -- row sweep 2.3 ms,
 // LDS / conversion 2.0 ms, MFMA 1.2 ms, loads 0.8 ms on 462 k x 1024 x 1024 -- instead of overlapping:
@@ -44,6 +44,13 @@ constexpr int H3_PIECE = H3_BM * HROW;    // bytes of one piece image (BM == BN)
 constexpr int H3_BUF = 4 * H3_PIECE;      // 2 X pieces + 2 W pieces: 64 KB
 constexpr int H3_MAIN = 2 * H3_BUF;       // (the epilogue's staging tiles, 34 KB, reuse it)
 constexpr int H3_LDS = H3_MAIN + H3_BM * 4;              // + inverse row scales
+
+#ifdef H3_STAMP
+__device__ unsigned long long g_h3_stamps[2][160];
+#define H3_ST(role, idx) do { if (stamp_on && lane == 0 && sti < 160) g_h3_stamps[role][sti] = __builtin_amdgcn_s_memtime(); ++sti; } while (0)
+#else
+#define H3_ST(role, idx) do { } while (0)
+#endif
 
 __device__ __forceinline__ int h3_off(int row, int chunk) { return row * HROW + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -89,78 +96,92 @@ __global__ void __launch_bounds__(512, 2) k_linear_h3(const LinearH3Args P) {
     }
     const int m0 = (tile / nb) * BM, n0 = (tile % nb) * BN;
     const int KT = (P.Kp + HBK - 1) / HBK;
+#ifdef H3_STAMP
+    const bool stamp_on = blockIdx.x == gridDim.x / 2 + 3 && (wid == 0 || wid == 4);
+    int sti = 0;
+#endif
+    H3_ST(wid >> 2, sti);
 
     if (wid >= 4) {
         // =================================== feeder waves ===================================
         const int ptid = tid - 256;
         const int a_kq = ptid & 15, a_row = ptid >> 4;        // 16 threads x 16 B per X row of a K step, 16 rows per pass
-        const int w_kb = ptid >> 7, w_n = ptid & 127;         // W word (piece i >> 2, k block w_kb + 2 (i & 3), column w_n)
         const float4 *__restrict__ X4 = reinterpret_cast<const float4 *>(A.x);
         const int64_t ldx4 = A.ldx >> 2;
-        const int64_t wpiece = (int64_t)(P.Kp / 8) * A.N;     // 16-byte words per packed piece
-        const f16x8 *__restrict__ W8 = reinterpret_cast<const f16x8 *>(P.wp + HHDR);
         float rscale[8];
+        // Loads are unconditional (row and k clamped into the matrix): a predicated load becomes a branch, and
+        // behind branches hipcc waits vmcnt(0) -- for the requests of BOTH register stages -- instead of a
+        // counted wait, which exposes a full memory round trip per K step.  Clamped elements are harmless:
+        // rows >= M are never stored, and the k >= K columns meet zero weights (the packed image is zero
+        // filled up to Kp, load_w supplies zeros beyond).
+        const int64_t xrow[8] = {
+            (int64_t)min(m0 + a_row, A.M - 1) * ldx4,       (int64_t)min(m0 + a_row + 16, A.M - 1) * ldx4,
+            (int64_t)min(m0 + a_row + 32, A.M - 1) * ldx4,  (int64_t)min(m0 + a_row + 48, A.M - 1) * ldx4,
+            (int64_t)min(m0 + a_row + 64, A.M - 1) * ldx4,  (int64_t)min(m0 + a_row + 80, A.M - 1) * ldx4,
+            (int64_t)min(m0 + a_row + 96, A.M - 1) * ldx4,  (int64_t)min(m0 + a_row + 112, A.M - 1) * ldx4};
+        const int k4max = (A.K >> 2) - 1;
+        auto load_tile = [&](float4 (&ra)[8], int kt) {
+            const int k4 = min(kt * (HBK / 4) + a_kq, k4max);
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int m = m0 + a_row + 16 * p;
-            float inv;
-            pow2_scale(m < A.M ? P.row_amax[m] : 0.f, rscale[p], inv);
-            if (a_kq == 0) rinv[a_row + 16 * p] = inv;
-        }
-        auto load_tile = [&](float4 (&ra)[8], f16x8 (&rb)[8], int kt) {
-            const int k0 = kt * HBK;
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int m = m0 + a_row + 16 * p, k = k0 + 4 * a_kq;
-                ra[p] = (m < A.M && k < A.K) ? X4[(int64_t)m * ldx4 + (k >> 2)] : f4_zero();
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int q = i >> 2, kb = (k0 >> 3) + w_kb + 2 * (i & 3), n = n0 + w_n;
-                f16x8 z;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
-                rb[i] = (n < A.N && kb < (P.Kp >> 3)) ? W8[q * wpiece + (int64_t)kb * A.N + n] : z;
-            }
+            for (int p = 0; p < 8; ++p) ra[p] = X4[xrow[p] + k4];
         };
-        auto store_tile = [&](const float4 (&ra)[8], const f16x8 (&rb)[8], char *buf) {
+        auto store_tile = [&](const float4 (&ra)[8], char *buf) {
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const float s = rscale[p];
-                const Split2 s0 = split2(ra[p].x * s), s1 = split2(ra[p].y * s), s2 = split2(ra[p].z * s),
-                             s3 = split2(ra[p].w * s);
-                f16x4 h1 = {s0.h1, s1.h1, s2.h1, s3.h1}, h2 = {s0.h2, s1.h2, s2.h2, s3.h2};
+                const f32x4v v = {ra[p].x * s, ra[p].y * s, ra[p].z * s, ra[p].w * s};
+                const f16x4 h1 = __builtin_convertvector(v, f16x4);
+                const f16x4 h2 = __builtin_convertvector(v - __builtin_convertvector(h1, f32x4v), f16x4);
                 char *dst = buf + h3_off(a_row + 16 * p, a_kq >> 1) + (a_kq & 1) * 8;
                 *reinterpret_cast<f16x4 *>(dst) = h1;
                 *reinterpret_cast<f16x4 *>(dst + PIECE) = h2;
             }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                *reinterpret_cast<f16x8 *>(buf + (2 + (i >> 2)) * PIECE + h3_off(w_n, w_kb + 2 * (i & 3))) = rb[i];
         };
         // register ring of two K steps; loads past the end re-read the last step (never stored)
         float4 xa0[8], xa1[8];
-        f16x8 wb0[8], wb1[8];
         const int last = KT - 1;
-        load_tile(xa0, wb0, 0);
-        load_tile(xa1, wb1, 1 < last ? 1 : last);
-        store_tile(xa0, wb0, smem_raw);                       // step 0 -> buffer 0
-        load_tile(xa0, wb0, 2 < last ? 2 : last);
+        load_tile(xa0, 0);                                    // the long-latency requests first
+        load_tile(xa1, 1 < last ? 1 : last);
+        {
+            float am[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int m = m0 + a_row + 16 * p;
+                am[p] = P.row_amax[m < A.M ? m : A.M - 1];
+            }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                float inv;
+                pow2_scale(m0 + a_row + 16 * p < A.M ? am[p] : 0.f, rscale[p], inv);
+                if (a_kq == 0) rinv[a_row + 16 * p] = inv;
+            }
+        }
+        H3_ST(1, sti);
+        store_tile(xa0, smem_raw);                            // step 0 -> buffer 0
+        H3_ST(1, sti);
+        load_tile(xa0, 2 < last ? 2 : last);
         lds_barrier();
+        H3_ST(1, sti);
         // step kt: the MFMA waves read buffer kt & 1; this half writes step kt + 1 into the other buffer
         // (registers (kt + 1) & 1) and re-requests those registers for step kt + 3
         for (int kt = 0; kt < KT; kt += 2) {
             if (kt + 1 < KT) {
-                store_tile(xa1, wb1, smem_raw + H3_BUF);
-                load_tile(xa1, wb1, kt + 3 < last ? kt + 3 : last);
+                store_tile(xa1, smem_raw + H3_BUF);
+                H3_ST(1, sti);
+                load_tile(xa1, kt + 3 < last ? kt + 3 : last);
+                H3_ST(1, sti);
             }
             lds_barrier();
+            H3_ST(1, sti);
             if (kt + 1 < KT) {
                 if (kt + 2 < KT) {
-                    store_tile(xa0, wb0, smem_raw);
-                    load_tile(xa0, wb0, kt + 4 < last ? kt + 4 : last);
+                    store_tile(xa0, smem_raw);
+                    H3_ST(1, sti);
+                    load_tile(xa0, kt + 4 < last ? kt + 4 : last);
+                    H3_ST(1, sti);
                 }
                 lds_barrier();
+                H3_ST(1, sti);
             }
         }
         lds_barrier();                                        // pairs with the barrier in front of the epilogue
@@ -181,9 +202,43 @@ __global__ void __launch_bounds__(512, 2) k_linear_h3(const LinearH3Args P) {
     // lane (row fi, k half fh) of a 32-row fragment tile; 32-row offsets keep (row >> 1) & 7 == (fi >> 1) & 7
     const int sw = (fi >> 1) & 7;
     const int arow = (wm0 + fi) * HROW, brow = 2 * PIECE + (wn0 + fi) * HROW;
+    // The packed W pieces of a K step (2 pieces x 8 k blocks x 128 columns of 16 B = 8 words per thread) are
+    // copied global -> registers -> LDS by THESE waves, at the head of the step, requested one step ahead: the
+    // feeder waves are the ones short of issue slots (measured: feeder copying W too 5.0 k cycles per step,
+    // this split 3.6 k, the copy spread between the MFMA groups 4.5 k).  Unconditional loads + select, as
+    // in the feeder.
+    const int w_kb = tid >> 7, w_n = tid & 127;               // word (piece i >> 2, k block w_kb + 2 (i & 3), column w_n)
+    const int64_t wpiece = (int64_t)(P.Kp / 8) * A.N;         // 16-byte words per packed piece
+    const f16x8 *__restrict__ W8 = reinterpret_cast<const f16x8 *>(P.wp + HHDR);
+    const int w_col = min(n0 + w_n, A.N - 1), kbmax = (P.Kp >> 3) - 1;
+    f16x8 wb[8];
+    auto load_w = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = i >> 2, kb = kt * (HBK / 8) + w_kb + 2 * (i & 3);
+            const f16x8 v = W8[q * wpiece + (int64_t)min(kb, kbmax) * A.N + w_col];
+            f16x8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
+            wb[i] = kb <= kbmax ? v : z;
+        }
+    };
+    auto store_w = [&](char *buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<f16x8 *>(buf + (2 + (i >> 2)) * PIECE + h3_off(w_n, w_kb + 2 * (i & 3))) = wb[i];
+    };
+    load_w(0);
+    store_w(smem_raw);
+    load_w(1 < KT ? 1 : 0);
     lds_barrier();                                            // buffer 0 is complete
+    H3_ST(0, sti);
     for (int kt = 0; kt < KT; ++kt) {
         const char *cur = smem_raw + (kt & 1) * H3_BUF;
+        if (kt + 1 < KT) {
+            store_w(smem_raw + ((kt & 1) ^ 1) * H3_BUF);      // free since the barrier that ended step kt - 1
+            load_w(kt + 2 < KT ? kt + 2 : kt + 1);
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int coff = ((2 * s + fh) ^ sw) << 4;
@@ -206,7 +261,9 @@ __global__ void __launch_bounds__(512, 2) k_linear_h3(const LinearH3Args P) {
             H3_TERM(acc1, 1, 0)
 #undef H3_TERM
         }
+        H3_ST(0, sti);
         lds_barrier();       // buffer kt & 1 fully read (rewritten during step kt + 1), buffer (kt + 1) & 1 complete
+        H3_ST(0, sti);
     }
     lds_barrier();                                            // every wave is done with the operand buffers
 
@@ -216,6 +273,7 @@ __global__ void __launch_bounds__(512, 2) k_linear_h3(const LinearH3Args P) {
         for (int j = 0; j < TN; ++j) acc0[i][j] += acc1[i][j];
     store_out<ACT, TM, TN, WN, false>(A, acc0, reinterpret_cast<float *>(smem_raw), m0 + wm0, n0 + wn0, wid, lane,
                                       rinv + wm0, winv);
+    H3_ST(0, sti);
 }
 
 template <int ACT>
@@ -245,7 +303,7 @@ extern "C" int blgnn_row_absmax(const float *x, int64_t ldx, int32_t M, int32_t 
 }
 
 extern "C" int blgnn_linear_h3(const float *x, int64_t ldx, const float *row_amax, const void *w_packed, float *y,
-                               int64_t ldy, int32_t M, int32_t N, int32_t K, const float *bias, const float *rowvec,
+                               int64_t ldy, float *y_row_amax, int32_t M, int32_t N, int32_t K, const float *bias, const float *rowvec,
                                const float *rowvec_w, int32_t act, const float *act_param,
                                const float *bn_scale, const float *bn_shift, void *stream) {
     BLGNN_CHECK_ARG(M >= 0 && N >= 0 && K > 0, "linear_h3: bad sizes");
@@ -263,7 +321,7 @@ extern "C" int blgnn_linear_h3(const float *x, int64_t ldx, const float *row_ama
     A.x = x; A.ldx = ldx; A.w = nullptr; A.ldw = 0; A.y = y; A.ldy = ldy;
     A.M = M; A.N = N; A.K = K; A.rowvec = rowvec; A.rowvec_w = rowvec_w;
     A.epi = Epilogue{bias, act_param, bn_scale, bn_shift, act};
-    A.vec_a = 1; A.vec_b = 0;
+    A.vec_a = 1; A.vec_b = 0; A.amax_out = y_row_amax;
     P.wp = reinterpret_cast<const _Float16 *>(w_packed);
     P.row_amax = row_amax;
     P.Kp = (K + 31) / 32 * 32;

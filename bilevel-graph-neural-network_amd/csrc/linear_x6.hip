@@ -177,7 +177,7 @@ extern "C" int blgnn_linear_x6(const float *x, int64_t ldx, const void *w_packed
     A.x = x; A.ldx = ldx; A.w = nullptr; A.ldw = 0; A.y = y; A.ldy = ldy;
     A.M = M; A.N = N; A.K = K; A.rowvec = rowvec; A.rowvec_w = rowvec_w;
     A.epi = Epilogue{bias, act_param, bn_scale, bn_shift, act};
-    A.vec_a = 1; A.vec_b = 0;
+    A.vec_a = 1; A.vec_b = 0; A.amax_out = nullptr;
     P.wp = reinterpret_cast<const __bf16 *>(w_packed);
     P.Kp = (K + 31) / 32 * 32;
     hipStream_t s = (hipStream_t)stream;

@@ -284,10 +284,13 @@ int blgnn_row_absmax(const float *x, int64_t ldx, int32_t M, int32_t K, float *o
  * split in two fp16 pieces, three MFMAs per product, see blgnn_gin_layer_h3).  Same call sites as
  * blgnn_linear (the GMN propagator's f_message / f_node MLPs, model/layers_gmn.py:19-26,39-47, are
  * the large ones); w_packed = blgnn_pack_weight_h3(W[K,N]); row_amax[m] >= max_k |x[m, k]| (any
- * value within a factor 2 above the true maximum gives the same result).  Needs K % 4 == 0,
+ * value within a factor 2 above the true maximum gives the same result).  y_row_amax (optional, [M],
+ * ZERO-INITIALISED by the caller) receives max_n |y[m, n]| through atomic maxima from the column
+ * tiles -- the row_amax of a following blgnn_linear_h3 on y, for free.  Needs K % 4 == 0,
  * ldx % 4 == 0 and 16-byte aligned x / w_packed, otherwise BLGNN_ERR_UNSUPPORTED (use blgnn_linear). */
 int blgnn_linear_h3(const float *x, int64_t ldx, const float *row_amax, const void *w_packed,
-                    float *y, int64_t ldy, int32_t M, int32_t N, int32_t K, const float *bias,
+                    float *y, int64_t ldy, float *y_row_amax, int32_t M, int32_t N, int32_t K,
+                    const float *bias,
                     const float *rowvec, const float *rowvec_w, int32_t act,
                     const float *act_param, const float *bn_scale, const float *bn_shift,
                     void *stream);

@@ -65,7 +65,7 @@ def spmm_sum(csr, x, self_coef=0.0, skip_self=False, w=None, out=None):
 
 
 def linear(x, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn_shift=None,
-           rowvec=None, rowvec_w=None, out=None, transform=None):
+           rowvec=None, rowvec_w=None, out=None, transform=None, row_amax=None, amax_out=None):
     if act not in real_ops.ACT_IDS:
         raise ValueError("Unknown activation function {}".format(act))
     v = x @ w_kn
@@ -74,6 +74,14 @@ def linear(x, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn
     if rowvec is not None:
         v = v + rowvec.view(-1, 1) * rowvec_w.view(1, -1)
     return _put(out, _epi(v, act, act_param, bn_scale, bn_shift))
+
+
+def linear_writes_amax(x, w_kn, transform=None):
+    return False
+
+
+def row_absmax(x, out=None):
+    return x.abs().amax(dim=1)
 
 
 def gin_layer_supported(csr, x, K, N):
@@ -164,7 +172,8 @@ def require_device(t, name="tensor"):
     return None
 
 
-NAMES = ["csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear", "gin_layer",
+NAMES = ["csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear", "linear_writes_amax", "row_absmax",
+         "gin_layer",
          "gin_layer_supported", "gin_layer_x6_supported", "gat_conv", "gcn_conv",
          "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum", "row_degree", "pair_gather_normalize", "link_pred_head",
          "l2_normalize_rows", "scatter_rows", "require_device"]

@@ -220,6 +220,27 @@ def test_linear_split_epilogue(device, act, transform):
     assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + N:].abs().max()) == 0.0
 
 
+def test_linear_f16x3_row_magnitudes(device):
+    """blgnn_row_absmax and the GEMM epilogue's fused row maxima (the normalisation input of the next
+    f16x3 GEMM) are exactly the row-wise max |.| of what was read / stored, N not a tile multiple"""
+    M, N, K = 33003, 200, 256
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, K, generator=g).to(device)
+    w = (torch.randn(K, N, generator=g) / 16).to(device)
+    b = torch.randn(N, generator=g).to(device)
+    assert torch.equal(ops.row_absmax(x), x.abs().amax(dim=1))
+    wide = torch.randn(M, K + 12, generator=g).to(device)
+    assert torch.equal(ops.row_absmax(wide[:, 4:4 + K]), wide[:, 4:4 + K].abs().amax(dim=1))
+    assert ops.linear_writes_amax(x, w, "f16x3")
+    am = torch.zeros(M, device=device)
+    y = ops.linear(x, w, b, act="tanh", transform="f16x3", amax_out=am)
+    assert torch.equal(am, y.abs().amax(dim=1))
+    # and it is a valid row_amax for the next GEMM
+    w2 = (torch.randn(N, 64, generator=g) / 8).to(device)
+    z = ops.linear(y, w2, transform="f16x3", row_amax=am)
+    assert max_err(z, y.double().cpu() @ w2.double().cpu()) < TOL
+
+
 @pytest.mark.parametrize("xs,ws", [(1e-6, 1.0), (3e4, 1.0), (1.0, 1e-5), (1.0, 300.0), (1e5, 1e-4)])
 def test_linear_f16x3_range(device, xs, ws):
     """per-row / per-matrix power-of-two normalisation of the f16x3 GEMM: tiny and huge activations and
