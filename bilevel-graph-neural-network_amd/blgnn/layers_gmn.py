@@ -12,13 +12,19 @@ What changes underneath (results equal to fp32 rounding):
     pair, an n1 x n2 x D temporary, S recomputed for the mirror) is one kernel.
   * f_node input cat(x, m_sum, u_sum) is never concatenated: producers write
     straight into column slices of one [Nn, 4D] buffer.
+  * m_sum itself is never formed: it only feeds f_node's first Linear (eval BN folded in),
+        f_in @ W1 = x @ W1[:D] + (S @ W2 + deg b2) @ W1[D:3D] + u_sum @ W1[3D:]
+                  = [x | S | u_sum] @ [W1[:D] ; W2 W1[D:3D] ; W1[3D:]] + deg (b2 W1[D:3D])
+    with S = sum_e relu(P_i + Q_j).  W2 W1[D:3D] is a product of WEIGHTS (formed once in
+    fp64, cached until a parameter changes), so the [Nn, 2D] x [2D, 2D] GEMM of every layer
+    disappears and the edge kernel writes S straight into the f_node input.
 """
 
 import torch
 import torch.nn as nn
 
 from . import ops
-from .layers_util import MLP, DerivedCache
+from .layers_util import MLP, DerivedCache, act_name
 
 __all__ = ["GMNPropagator"]
 
@@ -58,6 +64,26 @@ class GMNPropagator(nn.Module):
         w2 = self._cache.get("w2", lambda w: w.t().contiguous(), lin2.weight)
         return wpq, bpq, w2, lin2.bias
 
+    def _node_weights(self):
+        """f_node's first Linear (+ eval BN) with the message MLP's last Linear folded into its rows
+        D..3D: -> (w [4D, 4D], bias [4D], rank-1 column factor [4D]), cached."""
+        D = self.input_dim
+        lin2 = self.f_messasge.layers[1]
+        lin, bn = self.f_node.layers[0], self.f_node.bn[0]
+        if bn.training:
+            raise NotImplementedError("blgnn: train-mode BatchNorm is outside the forward-parity scope")
+
+        def compose(w2, b2, w, b, g, beta, mean, var):
+            scale = (g.double() / torch.sqrt(var.double() + bn.eps))
+            w1 = w.double().t() * scale.view(1, -1)                                   # [4D in, 4D out]
+            b1 = b.double() * scale + beta.double() - mean.double() * scale
+            mid = w1[D:3 * D]                                                         # rows fed by m_sum
+            wc = torch.cat([w1[:D], w2.double().t() @ mid, w1[3 * D:]], dim=0)
+            return wc.float().contiguous(), b1.float().contiguous(), (b2.double() @ mid).float().contiguous()
+
+        return self._cache.get("node1", compose, lin2.weight, lin2.bias, lin.weight, lin.bias, bn.weight,
+                               bn.bias, bn.running_mean, bn.running_var)
+
     def forward(self, ins, batch_data, model, edge_index=None):
         ops.require_device(ins, "ins")
         if self.f_node_name != 'MLP':
@@ -70,14 +96,19 @@ class GMNPropagator(nn.Module):
             csr = merge.csr()
         n, D = x.shape
         with torch.no_grad():
-            wpq, bpq, w2, b2 = self._message_weights()
+            wpq, bpq, _, _ = self._message_weights()
+            w1, b1, rw = self._node_weights()
             pq = ops.linear(x, wpq, bpq)                                  # [n, 4D] = [P | Q]
-            h = ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:])      # [n, 2D]
             f_in = torch.empty((n, 4 * D), dtype=torch.float32, device=x.device)
             f_in[:, :D].copy_(x)
-            ops.linear(h, w2, None, rowvec=ops.row_degree(csr), rowvec_w=b2, out=f_in[:, D:3 * D])
+            ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:], out=f_in[:, D:3 * D])
             ops.gmn_match(merge.segments(), x, out=f_in[:, 3 * D:])
-            out = self.f_node(f_in)
+            act = act_name(self.f_node.activation)
+            hid_amax = None
+            if ops.linear_writes_amax(f_in, w1):
+                hid_amax = torch.zeros(n, dtype=torch.float32, device=x.device)
+            hid = ops.linear(f_in, w1, b1, act=act, rowvec=ops.row_degree(csr), rowvec_w=rw, amax_out=hid_amax)
+            out = ops.linear(hid, self.f_node.weight_kn(1), self.f_node.layers[1].bias, row_amax=hid_amax)
         model.store_layer_output(self, out)
         return out
 

@@ -70,7 +70,10 @@ class LinkPred(nn.Module):
         ids1, ids2 = ids
         mlp = getattr(self, "mlp_concat", None)
         with torch.no_grad():
-            if (self.type == "mlp_concat" and len(mlp.layers) <= 4
+            # fused head for the interaction-level widths; wider graph embeddings (multi-scale readout of a
+            # lower-level-only model at d=256: 768 per graph) go through gather + the matrix-core GEMMs: the
+            # head's wide variant (one pair per wave, weights in LDS) took 1.55 ms for 8 192 pairs there
+            if (self.type == "mlp_concat" and len(mlp.layers) <= 4 and ins.shape[1] <= 256
                     and max(mlp.layer_channels) <= 2048 and act_name(mlp.activation) != "prelu"):
                 # fused head: gather + normalise + concat + MLP (+ sigmoid) in one launch
                 pair_preds = ops.link_pred_head(
