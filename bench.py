@@ -82,7 +82,9 @@ def parse():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="profiling aid: build rank 0's share of an N-GPU run on one GPU (no collective)")
     ap.add_argument("--fuse-lower", action="store_true",
-                    help="run the lower level as ONE launch (blgnn_gin_stack) instead of one per GIN layer")
+                    help="run the lower level as ONE launch (blgnn_gin_stack[_h3]) instead of one per GIN layer "
+                         "(default wherever the f16x3 stack applies: d=128)")
+    ap.add_argument("--no-fuse-lower", action="store_true", help="one launch per GIN layer + a readout launch")
     ap.add_argument("--transform", choices=("f16x3", "bf16x6", "f32"), default="f16x3",
                     help="how the dense transforms run: fp16 two-piece split (default), bf16 three-piece split, "
                          "or exact-f32 MFMA -- all fp32-equivalent")
@@ -387,12 +389,27 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
     ops.gin_layer = timer.wrap("f32", saved[0], work_f32, lambda *a, **kw: True)
     ops.gin_layer_x6 = timer.wrap("bf16x6", saved[1], work_split, lambda *a, **kw: True)
     ops.gin_layer_h3 = timer.wrap("f16x3", saved[2], work_split, lambda *a, **kw: True)
+    saved_stack = ops.gin_stack
+
+    def work_stack(csr, x0, tile_row, tile_mol, seg, layers, *a, **kw):
+        # the one-launch lower level: L x the per-layer algorithmic work (SURVEY 8d defines the bytes per
+        # layer as x read once + y written once + CSR; inside the stack the activations never leave LDS)
+        rows, K0 = x0.shape
+        N = layers[0]["N"] if "N" in layers[0] else layers[0]["w1"].shape[1]
+        fl = by = 0.0
+        for l in range(len(layers)):
+            K = K0 if l == 0 else N
+            fl += 2.0 * rows * (K * N + N * N)
+            by += 4.0 * rows * (K + N) + 4.0 * csr.nnz + 4.0 * (csr.n + 1)
+        return (fl, by)
+    ops.gin_stack = timer.wrap("stack", saved_stack, work_stack, lambda *a, **kw: True)
 
     big = cfg["drugs"] > 10000
     lower_cus = ({1: 20, 2: 16}.get(eff_world, 0) if not big else 0) if args.lower_cus < 0 else args.lower_cus
     engine = BiLevelEngine(model, lower_batch, template, graph, sharded=sharded_engine, world_size=engine_world,
                            use_graph=not args.no_graph, overlap=not args.no_overlap,
-                           fuse_lower=args.fuse_lower, readout_with_upper=args.readout_with_upper,
+                           fuse_lower=(False if args.no_fuse_lower else (True if args.fuse_lower else None)),
+                           readout_with_upper=args.readout_with_upper,
                            lower_cus_per_xcd=lower_cus)
     try:
         engine.capture()
@@ -429,6 +446,7 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
             timer.enabled = False
     finally:
         ops.gin_layer, ops.gin_layer_x6, ops.gin_layer_h3 = saved
+        ops.gin_stack = saved_stack
     pairs_per_step = batch * world
     res = {"value": pairs_per_step / (elapsed / steps), "ms_per_step": 1e3 * elapsed / steps,
            "timed_blocks": len(blocks), "ms_per_step_min": 1e3 * min(blocks) / steps,
@@ -442,6 +460,16 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
                       "parallelism": "molecule shards x%d + all-gather(pooled) + pair shards" % world}}
     if want_roofline and rank == 0:
         ms, work, names = timer.result()
+        if "stack" in names:
+            # the dominant launch is the one-launch lower level
+            sel = [i for i, n in enumerate(names) if n == "stack"]
+            mult, peak = MFMA_OF[transform if transform != "bf16x6" else "f32"]
+            kstack = ("k_gin_stack_h3 (whole lower level in one launch: %s GIN layers with CSR gather out of LDS, 2 GEMMs "
+                      "each as 3 fp16 MFMA products per fp32 product, act/BN and the per-layer readout; algorithmic work "
+                      "= L x the per-layer figure)" % flags.last_lower_lyr_num)
+            res["roofline"] = roofline_of(kstack, [ms[i] for i in sel], [work[i] for i in sel], mult, peak,
+                                          pmc_traffic("gin_stack_h3" + ("_cfg%d" % cfg_id if cfg_id != 1 else "")))
+            names = []
         mode = max(set(names), key=names.count) if names else transform
         mult, peak = MFMA_OF[mode]
         kname = {"f16x3": "k_gin_layer_h3 (fused GIN layer: CSR gather in LDS + 2 GEMMs as 3 fp16 MFMA products per "
@@ -451,9 +479,9 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
                  "f32": "k_gin_layer (fused GIN layer: CSR gather in LDS + 2 exact-f32 MFMA GEMMs + act/BN)"}[mode]
         tag = {"f16x3": "gin_layer_h3", "bf16x6": "gin_layer_x6", "f32": "gin_layer"}[mode]
         sel = [i for i, n in enumerate(names) if n == mode]
-        roofline = roofline_of(kname, [ms[i] for i in sel], [work[i] for i in sel], mult, peak,
-                               pmc_traffic(tag + ("_cfg%d" % cfg_id if cfg_id != 1 else "")))
-        res["roofline"] = roofline
+        if sel:
+            res["roofline"] = roofline_of(kname, [ms[i] for i in sel], [work[i] for i in sel], mult, peak,
+                                          pmc_traffic(tag + ("_cfg%d" % cfg_id if cfg_id != 1 else "")))
     engine.close()
     res["_cpu"] = lambda seconds: cpu_baseline_bilevel(ds, flags, model, lower_batch, template, batch, seconds)
     return res

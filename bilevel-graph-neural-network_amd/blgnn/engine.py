@@ -38,11 +38,10 @@ class FusedLowerStack(object):
     (``blgnn_gin_stack``), plus the per-layer path for the few molecules larger than a tile.
     Pooled rows are written straight into the interaction graph's ``init_x``.
 
-    Opt-in (``BiLevelEngine(fuse_lower=True)``): with the feature transform on the fp32 matrix
-    cores the stack is MFMA-bound either way, and whole-molecule tiles waste ~22 % of the MFMA
-    rows on padding and admit only two workgroups per CU, so it measures 228 us against
-    5 x 44 us for the per-layer kernels on the DrugBank-shape batch.  It
-    removes 4/5 of the activation traffic and will pay once the transform is faster."""
+    Opt-in (``BiLevelEngine(fuse_lower=True)``, ``bench.py --fuse-lower``).  With the f16x3 transform
+    (d = 128, F_in <= 128: ``blgnn_gin_stack_h3``) the launch takes 110 us for the DrugBank-shape sweep
+    against 5 x 29 us + 18 us of per-layer kernels + readout; other shapes take the exact-f32 stack (MFMA
+    bound: 228 us against 5 x 44 us)."""
 
     @staticmethod
     def supported(lower_layers, flags):
@@ -94,15 +93,24 @@ class FusedLowerStack(object):
         return BatchData(pairs, dataset, is_train=False, ignore_pairs=True)
 
     def _params(self):
+        from .config import FLAGS
+        h3 = (getattr(FLAGS, "feature_transform", "f16x3") == "f16x3" and self.n == 128
+              and self.convs[0].conv.nn[0].in_features <= 128)
         out = []
         for c in self.convs:
             lin1, lin2 = c.conv.nn[0], c.conv.nn[2]
             scale, shift = bn_affine(c._cache, "bn", c.bn)
-            out.append({
-                "w1": c._cache.get("w1", lambda w: w.t().contiguous(), lin1.weight), "b1": lin1.bias,
-                "w2": c._cache.get("w2", lambda w: w.t().contiguous(), lin2.weight), "b2": lin2.bias,
-                "act": act_name(c.act), "eps": c._cache.get("eps", lambda e: float(e[0]), c.conv.eps),
-                "slope": prelu_slopes(c._cache, "prelu", c.act, c.out_dim), "scale": scale, "shift": shift})
+            lay = {"b1": lin1.bias, "b2": lin2.bias,
+                   "act": act_name(c.act), "eps": c._cache.get("eps", lambda e: float(e[0]), c.conv.eps),
+                   "slope": prelu_slopes(c._cache, "prelu", c.act, c.out_dim), "scale": scale, "shift": shift}
+            if h3:      # f16x3 stack (blgnn_gin_stack_h3): range-normalised two-piece fp16 weight images
+                lay["w1p"] = c._cache.get("w1h", lambda w: ops.pack_weight_h3(w.t().contiguous()), lin1.weight)
+                lay["w2p"] = c._cache.get("w2h", lambda w: ops.pack_weight_h3(w.t().contiguous()), lin2.weight)
+                lay["N"] = self.n
+            else:
+                lay["w1"] = c._cache.get("w1", lambda w: w.t().contiguous(), lin1.weight)
+                lay["w2"] = c._cache.get("w2", lambda w: w.t().contiguous(), lin2.weight)
+            out.append(lay)
         return out
 
     def run(self, model, init_x):
@@ -112,6 +120,8 @@ class FusedLowerStack(object):
                 ops.gin_stack(m.csr(), m.x, self.tile_row, self.tile_mol, m.segments(), self._params(),
                               init_x, self.pool_cols, self.agg.agg_func.kind, row_map=self.rows_small)
             if self.large is not None:                       # molecules bigger than a tile: per-layer kernels
+                # (on the same stream: forked onto a side stream inside the captured graph the chain lost the
+                # launch stream's CU mask and the step got slower, 0.25 vs 0.21 ms)
                 model.acts = [self.large.merge_data['merge'].x]
                 for layer in self.layers_all:
                     model.acts.append(layer(model.acts[-1], self.large, model))
@@ -123,7 +133,7 @@ class BiLevelEngine(object):
     ``step(pairs)`` with an int array ``[B, 2]`` of graph ids scores those pairs."""
 
     def __init__(self, model, lower_batch, upper_batches, graph, sharded=None, world_size=1,
-                 use_graph=True, overlap=True, fuse_lower=False, readout_with_upper=None, lower_cus_per_xcd=None):
+                 use_graph=True, overlap=True, fuse_lower=None, readout_with_upper=None, lower_cus_per_xcd=None):
         from .config import FLAGS
         k = FLAGS.last_lower_lyr_num
         self.model = model
@@ -166,6 +176,11 @@ class BiLevelEngine(object):
                 self._row_lut = lut
         gids = lower_batch._graph_gids
         self.fused = None
+        if fuse_lower is None:
+            # Opt-in.  The f16x3 stack (d = 128) needs 110 us for the DrugBank-shape sweep against 5 x 29 + 18 us
+            # for the per-layer kernels + readout, but the per-layer chain of the few molecules larger than a tile
+            # then runs behind it and the PIPELINED step is slower (0.206 vs 0.190 ms: DESIGN.md section 4).
+            fuse_lower = False
         if fuse_lower and FusedLowerStack.supported(self.lower_layers, FLAGS) and \
                 base.shape[1] == self.lower_layers[0].out_dim * (len(self.lower_layers) - 1
                                                                  if self.lower_layers[-1].concat_multi_scale else 1):

@@ -228,12 +228,14 @@ def gin_stack(csr, x0, tile_row, tile_mol, seg, layers, pooled, pool_cols, kind=
               y_last=None):
     """L stacked GIN layers + per-layer readout in one launch (include/blgnn.h: blgnn_gin_stack).
     ``layers``: list of dicts with w1 [K,N], b1, w2 [N,N], b2, act (name), eps, and optional
-    slope / scale / shift; ``pool_cols[l]`` = column offset in ``pooled`` or -1."""
+    slope / scale / shift; ``pool_cols[l]`` = column offset in ``pooled`` or -1.  Dicts that carry
+    ``w1p`` / ``w2p`` (pack_weight_h3 images) and ``N`` instead of w1 / w2 select the f16x3 stack
+    (blgnn_gin_stack_h3: N == 128, K0 <= 128)."""
     import ctypes
     xp, ldx0 = _mat(x0, "x0")
     K0 = x0.shape[1]
     L = len(layers)
-    N = int(layers[0]["w1"].shape[1])
+    N = int(layers[0]["N"]) if "N" in layers[0] else int(layers[0]["w1"].shape[1])
     T = tile_row.numel() - 1
 
     def table(key, required=False):
@@ -241,9 +243,16 @@ def gin_stack(csr, x0, tile_row, tile_mol, seg, layers, pooled, pool_cols, kind=
 
     pp, ldp = _mat(pooled, "pooled") if pooled is not None else (None, 0)
     yp, ldy = _mat(y_last, "y_last") if y_last is not None else (None, 0)
-    call("blgnn_gin_stack", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, xp, ldx0, K0, N, T,
+    packed = all("w1p" in lay and "w2p" in lay for lay in layers)
+    if packed:                                               # f16x3 stack: packed fp16 weight images
+        w1t = (ctypes.c_void_p * L)(*[lay["w1p"].data_ptr() for lay in layers])
+        w2t = (ctypes.c_void_p * L)(*[lay["w2p"].data_ptr() for lay in layers])
+    else:
+        w1t, w2t = table("w1", True), table("w2", True)
+    call("blgnn_gin_stack_h3" if packed else "blgnn_gin_stack", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz,
+         xp, ldx0, K0, N, T,
          _vec(tile_row, "tile_row", torch.int32, False), _vec(tile_mol, "tile_mol", torch.int32, False),
-         _vec(seg, "seg", torch.int32, False), L, table("w1", True), table("b1"), table("w2", True),
+         _vec(seg, "seg", torch.int32, False), L, w1t, table("b1"), w2t,
          table("b2"), table("slope"), table("scale"), table("shift"),
          (ctypes.c_int32 * L)(*[_act(lay["act"]) for lay in layers]),
          (ctypes.c_float * L)(*[float(lay.get("eps", 0.0)) for lay in layers]),

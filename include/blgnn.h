@@ -176,6 +176,22 @@ int blgnn_gin_stack(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                     int64_t ldp, const int32_t *row_map, float *y_last, int64_t ldy,
                     void *stream);
 
+/* blgnn_gin_stack with both dense transforms of every layer on the fp16 matrix cores at fp32 accuracy
+ * (f16x3, see blgnn_gin_layer_h3): w1_packed_host / w2_packed_host are HOST arrays of num_layers device
+ * pointers to blgnn_pack_weight_h3 images.  N == 128, K0 <= 128; 64-row whole-molecule tiles, two
+ * workgroups per CU; the per-layer readout (model/layers_aggregation.py:32-41) is part of the launch. */
+int blgnn_gin_stack_h3(const int32_t *rowptr, const int32_t *col, int64_t nnz, const float *x0,
+                       int64_t ldx0, int32_t K0, int32_t N, int32_t num_tiles,
+                       const int32_t *tile_row, const int32_t *tile_mol, const int32_t *seg,
+                       int32_t num_layers, const void *const *w1_packed_host,
+                       const float *const *b1_host, const void *const *w2_packed_host,
+                       const float *const *b2_host, const float *const *slope_host,
+                       const float *const *scale_host, const float *const *shift_host,
+                       const int32_t *act_host, const float *eps_host,
+                       const int32_t *pool_col_host, int32_t reduce_kind, float *pooled,
+                       int64_t ldp, const int32_t *row_map, float *y_last, int64_t ldy,
+                       void *stream);
+
 /* GCNConv: model/layers.py:23,52 (formula documented at
  * model/layers_meta.py:128-148).  Step 1: dis[i] = (1 + sum_{j!=i} w_ij)^-1/2
  * (inf -> 0).  */

@@ -331,6 +331,50 @@ def test_gin_stack_fused_lower_level(device, K0, N, L):
     assert ops.molecule_tiles([10, 70, 3], 64) is None
 
 
+@pytest.mark.parametrize("K0,N,L,act0", [(52, 128, 5, "relu"), (128, 128, 2, "prelu"), (24, 128, 3, "relu"), (100, 128, 1, "identity")])
+def test_gin_stack_f16x3(device, K0, N, L, act0):
+    """the f16x3 stack (blgnn_gin_stack_h3): L GIN layers with both GEMMs on the fp16 matrix cores + multi-scale
+    readout in one launch == layer-by-layer fp64 oracle"""
+    ds = blgnn.make_synthetic(90, 10, seed=K0 + N, device="cpu")
+    keep = [g for g in ds.molecules.gids if ds.molecules.sizes[ds.molecules.gid_to_pos[g]] <= 64]
+    merged = ds.molecules.merge(keep)
+    m = merged["merge"]
+    n, G = m.x.shape[0], len(keep)
+    sizes = np.asarray([b - a for a, b in merged["ind_list"]])
+    g = torch.Generator().manual_seed(L)
+    x0 = torch.randn(n, K0, generator=g)
+    layers, x64, pooled_ref = [], x0.double(), []
+    for l in range(L):
+        K = K0 if l == 0 else N
+        act = act0 if l < L - 1 else "identity"
+        slope = torch.rand(N, generator=g)
+        w1, b1 = torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g) * 0.1
+        w2, b2 = torch.randn(N, N, generator=g) / N ** 0.5, torch.randn(N, generator=g) * 0.1
+        scale, shift = torch.rand(N, generator=g) * 0.5 + 0.25, torch.randn(N, generator=g) * 0.1
+        D = lambda t: t.double()
+        x64 = oracle.apply_act(oracle.gin_conv(x64, m.edge_index, D(w1), D(b1), D(w2), D(b2), act, prelu_weight=D(slope)), act, D(slope)) * D(scale) + D(shift)
+        pooled_ref.append(oracle.scatter_mean(x64, m.batch, G))
+        dv = lambda t: t.contiguous().to(device)
+        layers.append({"w1p": ops.pack_weight_h3(dv(w1.t())), "b1": dv(b1), "w2p": ops.pack_weight_h3(dv(w2.t())),
+                       "b2": dv(b2), "N": N, "act": act, "eps": 0.0, "slope": dv(slope) if act == "prelu" else None,
+                       "scale": dv(scale), "shift": dv(shift)})
+    tiles = ops.molecule_tiles(sizes, 64)
+    assert tiles is not None and int(np.diff(tiles[0]).max()) <= 64
+    csr = ops.csr_from_edge_index(m.edge_index.to(device), n)
+    seg = torch.as_tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=device)
+    pooled = torch.zeros(G + 3, L * N + 8, device=device)
+    rows = torch.arange(G, dtype=torch.int32, device=device).flip(0) + 3           # scattered output rows
+    y_last = torch.empty(n, N, device=device)
+    ops.gin_stack(csr, x0.to(device), torch.as_tensor(tiles[0], device=device), torch.as_tensor(tiles[1], device=device),
+                  seg, layers, pooled[:, 4:4 + L * N], [l * N for l in range(L)], "mean", row_map=rows, y_last=y_last)
+    ref = torch.cat(pooled_ref, dim=1)
+    assert max_err(pooled[rows.long(), 4:4 + L * N], ref) < TOL
+    assert max_err(y_last, x64) < TOL
+    assert float(pooled[:3].abs().max()) == 0.0 and float(pooled[:, :4].abs().max()) == 0.0
+
+
+
+
 @pytest.mark.parametrize("K,N,act", [(52, 128, "relu"), (128, 128, "relu"), (128, 128, "identity"), (40, 256, "relu"),
                                      (256, 256, "relu"), (256, 128, "prelu"), (64, 256, "tanh")])
 def test_gin_layer_bf16x6(device, K, N, act):
