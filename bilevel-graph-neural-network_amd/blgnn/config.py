@@ -64,7 +64,7 @@ def make_flags(model="higher_level_gnn", dataset="drugbank", lower_level_gnn_typ
                higher_level_gnn_type="gat", D_lower=64, D_higher=64,
                lower_level_num_layers=None, higher_level_num_layers=3, batch_size=None,
                device="cuda:0", node_aggr=None, bn=True, gnn_normalize=False,
-               gat_softmax_group="src", d_init=64, feature_transform="f16x3"):
+               gat_softmax_group="src", d_init=64, feature_transform="f16x3", multi_edge_node_model="gat"):
     """Reproduce the flag values and layer list of src/config.py for ``model``.
     Defaults are the reference's (config.py:96,126-131,180,237-238)."""
     if model not in MODELS:
@@ -76,7 +76,8 @@ def make_flags(model="higher_level_gnn", dataset="drugbank", lower_level_gnn_typ
     if lower_level_num_layers is None:
         lower_level_num_layers = 3 if gmn else 5
     different_edge_type_aggr = drugcombo          # config.py:77-83
-    node_model = "gat_multi_edge_aggr" if different_edge_type_aggr else None
+    # config.py:120-123 hard-codes 'gat_multi_edge_aggr'; model/layers_meta.py:68 also builds 'gcn'
+    node_model = ("%s_multi_edge_aggr" % multi_edge_node_model) if different_edge_type_aggr else None
     edge_model = "none" if different_edge_type_aggr else None
     batch_unique_graphs = model != "lower_level_gmn"
     if node_aggr is None:

@@ -1,7 +1,7 @@
 """``MetaLayerWrapper`` with ``node_model='gat_multi_edge_aggr'`` (the DrugCombo
-upper level) -- drop-in for the reachable part of model/layers_meta.py.
+upper level) or ``'gcn_multi_edge_aggr'`` -- drop-in for the reachable part of model/layers_meta.py.
 
-out = act( sum_k GATConv_k(x, edge_index_k) ): each edge type accumulates into the
+out = act( sum_k GATConv_k(x, edge_index_k) ) (or GCNConv_k): each edge type accumulates into the
 same output buffer inside the aggregation kernel's epilogue; the activation is
 applied by the last edge type's pass.  ``EdgeModel`` / ``NodeModel`` / ``*ConvEdge``
 are only reachable with ``use_interaction_edge_attrs=True``, which src/config.py:77-83
@@ -44,8 +44,9 @@ class NodeModelAggrByEdge(nn.Module):
                 out = ops.gat_conv(g.csr(), x, c.weight, c.att, c.bias,
                                    group=getattr(FLAGS, "gat_softmax_group", "src"),
                                    slope=c.negative_slope, act=act, out=out, accumulate=i > 0)
-            else:
-                raise NotImplementedError("gcn_multi_edge_aggr: accumulate epilogue is GAT-only for now")
+            else:                                            # 'gcn': model/layers_meta.py:68,74-79
+                c = self.GNNS[i]
+                out = ops.gcn_conv(g.csr(), x, c.weight, c.bias, act=act, out=out, accumulate=i > 0)
         return out
 
 

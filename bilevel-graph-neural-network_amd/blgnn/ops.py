@@ -392,7 +392,7 @@ def gat_conv(csr, x, weight, att, bias, group="src", slope=0.2, act="identity", 
 
 
 def gcn_conv(csr, x, weight, bias, edge_weight=None, act="identity", act_param=None,
-             bn_scale=None, bn_shift=None, out=None):
+             bn_scale=None, bn_shift=None, out=None, accumulate=False):
     h = linear(x, weight)
     n, d = h.shape
     hp, ldh = _mat(h, "h")
@@ -405,7 +405,7 @@ def gcn_conv(csr, x, weight, bias, edge_weight=None, act="identity", act_param=N
     yp, ldy = _mat(y, "out")
     call("blgnn_gcn_aggregate", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, wp, dis.data_ptr(), hp,
          ldh, yp, ldy, n, d, _vec(bias, "bias"), _act(act), _vec(act_param, "act_param"),
-         _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), s)
+         _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), int(bool(accumulate)), s)
     return y
 
 

@@ -815,7 +815,7 @@ extern "C" int blgnn_gcn_aggregate(const int32_t *rowptr, const int32_t *col, in
                                    const float *dis, const float *h, int64_t ldh, float *y,
                                    int64_t ldy, int32_t n, int32_t d, const float *bias,
                                    int32_t act, const float *act_param, const float *bn_scale,
-                                   const float *bn_shift, void *stream) {
+                                   const float *bn_shift, int32_t accumulate, void *stream) {
     if (int rc = check_csr(rowptr, col, n, nnz, "gcn_aggregate")) return rc;
     BLGNN_CHECK_ARG(d >= 0 && (n == 0 || d == 0 || (h && y && dis)), "gcn_aggregate: null pointer");
     BLGNN_CHECK_ARG(ldh >= d && ldy >= d, "gcn_aggregate: leading dimension < d");
@@ -825,6 +825,7 @@ extern "C" int blgnn_gcn_aggregate(const int32_t *rowptr, const int32_t *col, in
     A.rowptr = rowptr; A.col = col; A.x = h; A.ldx = ldh; A.y = y; A.ldy = ldy; A.n = n; A.d = d;
     A.w = w; A.dis = dis;
     A.epi = Epilogue{bias, act_param, bn_scale, bn_shift, act};
+    A.accumulate = accumulate;
     return dispatch<MODE_GCN>(A, nnz, true, (hipStream_t)stream, "gcn_aggregate");
 }
 

@@ -197,15 +197,17 @@ int blgnn_gin_stack_h3(const int32_t *rowptr, const int32_t *col, int64_t nnz, c
  * (inf -> 0).  */
 int blgnn_gcn_deg_inv_sqrt(const int32_t *rowptr, const int32_t *col,
                            const float *w, int32_t n, float *dis, void *stream);
-/* Step 2: y[i] = epi( dis_i^2 h_i + sum_{j!=i} dis_i w_ij dis_j h_j + bias ),
+/* Step 2: y[i] = epi( dis_i^2 h_i + sum_{j!=i} dis_i w_ij dis_j h_j + bias [+ y[i]] ),
  * epi = activation then optional per-channel affine (eval BatchNorm:
- * model/layers.py:55-57).  bias/act_param/bn_scale/bn_shift may be NULL. */
+ * model/layers.py:55-57).  bias/act_param/bn_scale/bn_shift may be NULL.
+ * accumulate != 0 adds the previous contents of y before the activation: the sum over edge types
+ * of NodeModelAggrByEdge('gcn') (model/layers_meta.py:68,74-79) without a temporary per type. */
 int blgnn_gcn_aggregate(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                         const float *w, const float *dis, const float *h,
                         int64_t ldh, float *y, int64_t ldy, int32_t n, int32_t d,
                         const float *bias, int32_t act, const float *act_param,
                         const float *bn_scale, const float *bn_shift,
-                        void *stream);
+                        int32_t accumulate, void *stream);
 
 /* GATConv heads=1: model/layers.py:33,54; model/layers_meta.py:70,78.
  * Step 1: s_dst[i] = h_i . att[0:d], s_src[i] = h_i . att[d:2d]. */

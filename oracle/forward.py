@@ -142,10 +142,13 @@ def run_layers(specs, sd, plain, flags, first=0, x0=None):
             params, k2 = [], 0
             while p + ".node_model.GNNS.%d.weight" % k2 in sd:
                 q = p + ".node_model.GNNS.%d" % k2
-                params.append((sd[q + ".weight"], sd[q + ".att"], sd[q + ".bias"]))
+                params.append((sd[q + ".weight"], sd.get(q + ".att"), sd[q + ".bias"]))
                 k2 += 1
-            out = ops.multi_edge_gat(x, plain["hl_edges"], params,
-                                     flags.get("softmax_group", "src"))
+            if params[0][1] is None:                 # NodeModelAggrByEdge('gcn'): model/layers_meta.py:68,74-79
+                out = sum(ops.gcn_conv(x, ei, w, b) for ei, (w, _, b) in zip(plain["hl_edges"], params))
+            else:
+                out = ops.multi_edge_gat(x, plain["hl_edges"], params,
+                                         flags.get("softmax_group", "src"))
             out = ops.apply_act(out, info["act"])
         elif name == "LinkPredictor":
             ids = plain["pair_ids"]

@@ -111,8 +111,10 @@ def gat_conv(csr, x, weight, att, bias, group="src", slope=0.2, act="identity", 
 
 
 def gcn_conv(csr, x, weight, bias, edge_weight=None, act="identity", act_param=None,
-             bn_scale=None, bn_shift=None, out=None):
+             bn_scale=None, bn_shift=None, out=None, accumulate=False):
     v = oracle.gcn_conv(x, csr.edge_index, weight, bias, edge_weight)
+    if accumulate:
+        v = v + out
     return _put(out, _epi(v, act, act_param, bn_scale, bn_shift))
 
 

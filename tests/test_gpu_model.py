@@ -143,10 +143,11 @@ def test_mhcaddi_gmn_forward(device):
         assert max_err(got, ref) < TOL
 
 
-def test_drugcombo_meta_forward(device):
+@pytest.mark.parametrize("node_model", ["gat", "gcn"])
+def test_drugcombo_meta_forward(device, node_model):
     ds = blgnn.make_synthetic(70, 500, seed=8, device=device, num_edge_types=2, name="drugcombo_syn")
     flags = blgnn.make_flags("lower_level_gnn_higher_level", dataset="drugcombo", lower_level_gnn_type="gin",
-                             device=device)
+                             device=device, multi_edge_node_model=node_model)
     model, data = build(flags, ds, seed=11, num_hyper_edge_feat=3)
     specs = layer_specs(flags)
     pairs = _pairs(ds, 32)
