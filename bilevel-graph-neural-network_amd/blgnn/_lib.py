@@ -57,6 +57,7 @@ SIGNATURES = {
     "blgnn_linear": [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p, _p],
     "blgnn_gat_transform": [_p, _i64, _p, _i64, _p, _i32, _i32, _i32, _p, _i64, _p, _p, _p],
     "blgnn_linear_x6": [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p, _p],
+    "blgnn_pack_weight_h3g": [_p, _i64, _i32, _i32, _p, _p],
     "blgnn_row_absmax": [_p, _i64, _i32, _i32, _p, _p],
     "blgnn_linear_h3": [_p, _i64, _p, _p, _p, _i64, _p, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p, _p],
     "blgnn_gmn_match": [_p, _i32, _p, _i64, _p, _i64, _i32, _p],
@@ -68,7 +69,7 @@ SIGNATURES = {
     "blgnn_stream_destroy": [_p],
 }
 LIBRARY_SYMBOLS = ["blgnn_version", "blgnn_last_error", "blgnn_device_count", "blgnn_packed_weight_x6_elems",
-                   "blgnn_packed_weight_h3_elems"]
+                   "blgnn_packed_weight_h3_elems", "blgnn_packed_weight_h3g_elems"]
 
 _lib = None
 
@@ -99,6 +100,8 @@ def load():
     lib.blgnn_packed_weight_x6_elems.restype = ctypes.c_int64
     lib.blgnn_packed_weight_h3_elems.argtypes = [_i32, _i32]
     lib.blgnn_packed_weight_h3_elems.restype = ctypes.c_int64
+    lib.blgnn_packed_weight_h3g_elems.argtypes = [_i32, _i32]
+    lib.blgnn_packed_weight_h3g_elems.restype = ctypes.c_int64
     _lib = lib
     return lib
 

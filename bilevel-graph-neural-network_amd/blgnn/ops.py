@@ -16,7 +16,7 @@ from .config import FLAGS
 __all__ = [
     "CSR", "csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear",
     "gat_conv", "gcn_conv", "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum", "row_absmax", "linear_writes_amax", "linear_h3_preferred",
-    "row_degree", "link_pred_head", "pack_weight_x6", "pack_weight_h3", "gin_layer_h3", "gin_layer_h3_supported", "linear_x6_supported", "gin_layer_x6", "gin_layer_x6_supported", "gin_stack", "molecule_tiles", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
+    "row_degree", "link_pred_head", "pack_weight_x6", "pack_weight_h3", "pack_weight_h3g", "gin_layer_h3", "gin_layer_h3_supported", "linear_x6_supported", "gin_layer_x6", "gin_layer_x6_supported", "gin_stack", "molecule_tiles", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
     "require_device",
 ]
 
@@ -169,6 +169,16 @@ def pack_weight_h3(w_kn):
     return out
 
 
+def pack_weight_h3g(w_kn):
+    """[K, N] fp32 weights -> the tile-ordered two-piece fp16 image the f16x3 GEMM (linear) reads."""
+    wp, ldw = _mat(w_kn, "w")
+    K, N = w_kn.shape
+    out = torch.empty(int(_lib.load().blgnn_packed_weight_h3g_elems(K, N)), dtype=torch.float16,
+                      device=w_kn.device)
+    call("blgnn_pack_weight_h3g", wp, ldw, K, N, out.data_ptr(), _stream())
+    return out
+
+
 def gin_layer_h3_supported(csr, x, K, N):
     return (N == 128 and K % 4 == 0 and K <= 128 and x.stride(0) % 4 == 0
             and x.data_ptr() % 16 == 0 and csr.nnz < 12 * max(csr.n, 1))
@@ -279,7 +289,7 @@ def _packed_weight(w_kn, kind="x6"):
     if len(_PACKED) > 512:
         for k in [k for k, v in _PACKED.items() if v[0]() is None]:
             del _PACKED[k]
-    packed = pack_weight_h3(w_kn) if kind == "h3" else pack_weight_x6(w_kn)
+    packed = pack_weight_h3g(w_kn) if kind == "h3g" else pack_weight_x6(w_kn)
     _PACKED[key] = (weakref.ref(w_kn), stamp, packed)
     return packed
 
@@ -341,7 +351,7 @@ def linear(x, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn
             if row_amax is None:
                 row_amax = row_absmax(x)
             call("blgnn_linear_h3", xp, ldx, _vec(row_amax, "row_amax", optional=False),
-                 _packed_weight(w_kn, "h3").data_ptr(), yp, ldy, _vec(amax_out, "amax_out"), M, N, K,
+                 _packed_weight(w_kn, "h3g").data_ptr(), yp, ldy, _vec(amax_out, "amax_out"), M, N, K,
                  _vec(bias, "bias"),
                  _vec(rowvec, "rowvec"), _vec(rowvec_w, "rowvec_w"), _act(act), _vec(act_param, "act_param"),
                  _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), _stream())

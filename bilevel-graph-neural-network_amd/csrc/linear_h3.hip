@@ -3,7 +3,7 @@
 //
 //   Y = epi( X[M,K] @ W[K,N] + bias + rowvec (x) rowvec_w )      epi = act, then affine
 //
-// Same contract as blgnn_linear; W arrives range-normalised, split and packed (blgnn_pack_weight_h3).
+// Same contract as blgnn_linear; W arrives range-normalised, split and packed (blgnn_pack_weight_h3g).
 // These are the GEMMs of the GMN propagator (model/layers_gmn.py:19-26,39-47: f_message, f_node) and
 // every other nn.Linear / x @ W of the path once M is large.
 //
@@ -14,7 +14,7 @@
 // Structure: one 512-thread workgroup per CU, block tile 128 x 128, K step 64, ROLE SPLIT:
 //   waves 0-3 (one per SIMD) only read operand fragments from LDS and issue MFMAs (2 x 2 tiles of
 //             32 x 32 each, 48 MFMAs per K step) and own the epilogue;
-//             They also copy the packed W pieces of the next step global -> registers -> LDS.
+//             They also fetch the W tile image of the next step by LDS-DMA (32 linear 1 KB pieces).
 //   waves 4-7 (the second wave of each SIMD) own the X operand and all vector work: X tile fp32 ->
 //             registers (requested three K steps ahead) -> scale -> split -> two fp16 images in LDS.
 // One barrier per K step, two LDS buffers of 64 KB.  A measured knock-out of the single-role version
@@ -32,9 +32,9 @@ namespace blgnn {
 
 struct LinearH3Args {
     LinearArgs base;             // x, ldx, y, ldy, M, N, K, rowvec, rowvec_w, epi (w / ldw unused)
-    const _Float16 *wp;          // header (inverse scale) + pieces [2][Kp/8][N][8]
+    const _Float16 *wp;          // blgnn_pack_weight_h3g image: header (inverse scale) + 32 KB tile images
     const float *row_amax;       // [M] largest magnitude of every X row
-    int32_t Kp;                  // K rounded up to 32
+    int32_t KS;                  // K steps of 64
 };
 
 constexpr int HBK = 64;                   // K step
@@ -53,6 +53,50 @@ __device__ unsigned long long g_h3_stamps[2][160];
 #endif
 
 __device__ __forceinline__ int h3_off(int row, int chunk) { return row * HROW + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// ---- weight packing for this kernel: W[K,N] fp32 -> header + [N / 128][K / 64] tile images of 32 KB ----------
+// A tile image is byte for byte what the kernel wants in LDS for one (column block, K step):
+// [piece 2][column 128][chunk' 8][8 fp16] with chunk' = chunk ^ ((column >> 1) & 7) -- so the MFMA waves
+// fetch it with 32 linear LDS-DMA instructions of 1 KB (global_load_lds_dwordx4: no registers, no ds_write)
+// and read fragments from it without bank conflicts.  Scaled by the power of two that moves the largest
+// |w| into [2^14, 2^15) (inverse in the header); zero filled past K and N.
+typedef __attribute__((address_space(3))) void h3_lds_void;
+typedef __attribute__((address_space(1))) void h3_glb_void;
+constexpr int H3_WTILE = 2 * 128 * 128;          // bytes of one tile image
+
+__global__ void k_pack_h3g(const float *__restrict__ w, int64_t ldw, int K, int N, int KS,
+                           const unsigned *__restrict__ amax_bits, _Float16 *__restrict__ out) {
+    float scale, inv;
+    pow2_scale(__uint_as_float(*amax_bits), scale, inv);
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one 16-byte word of piece 0 AND piece 1
+    if (idx == 0) *reinterpret_cast<float *>(out) = inv;
+    const int NB = (N + 127) / 128;
+    if (idx >= (int64_t)NB * KS * 128 * 8) return;
+    const int cp = (int)(idx & 7), r = (int)((idx >> 3) & 127);
+    const int64_t tile = idx >> 10;
+    const int ks = (int)(tile % KS), nb = (int)(tile / KS);
+    const int c = cp ^ ((r >> 1) & 7), n = nb * 128 + r;
+    f16x8 p[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = ks * 64 + c * 8 + j;
+        const Split2 sp = split2((k < K && n < N) ? w[(int64_t)k * ldw + n] * scale : 0.f);
+        p[0][j] = sp.h1; p[1][j] = sp.h2;
+    }
+    _Float16 *base = out + HHDR + tile * (H3_WTILE / 2);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        *reinterpret_cast<f16x8 *>(base + ((q * 128 + r) * 8 + cp) * 8) = p[q];
+}
+
+__global__ void k_absmax_g(const float *__restrict__ w, int64_t ldw, int K, int N, unsigned *out) {
+    float m = 0.f;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < (int64_t)K * N;
+         idx += (int64_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(w[(idx / N) * ldw + idx % N]));
+    m = group_max(m, WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0) atomicMax(out, __float_as_uint(m));   // non-negative floats order as uints
+}
 
 // ---- row maxima: out[m] = max_k |x[m, k]|, one wave per row -------------------------------------------------
 __global__ void __launch_bounds__(256) k_row_absmax(const float *__restrict__ x, int64_t ldx, int M, int K,
@@ -95,7 +139,7 @@ __global__ void __launch_bounds__(512, 2) k_linear_h3(const LinearH3Args P) {
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
     const int m0 = (tile / nb) * BM, n0 = (tile % nb) * BN;
-    const int KT = (P.Kp + HBK - 1) / HBK;
+    const int KT = P.KS;
 #ifdef H3_STAMP
     const bool stamp_on = blockIdx.x == gridDim.x / 2 + 3 && (wid == 0 || wid == 4);
     int sti = 0;
@@ -113,7 +157,7 @@ __global__ void __launch_bounds__(512, 2) k_linear_h3(const LinearH3Args P) {
         // behind branches hipcc waits vmcnt(0) -- for the requests of BOTH register stages -- instead of a
         // counted wait, which exposes a full memory round trip per K step.  Clamped elements are harmless:
         // rows >= M are never stored, and the k >= K columns meet zero weights (the packed image is zero
-        // filled up to Kp, load_w supplies zeros beyond).
+        // filled past K).
         const int64_t xrow[8] = {
             (int64_t)min(m0 + a_row, A.M - 1) * ldx4,       (int64_t)min(m0 + a_row + 16, A.M - 1) * ldx4,
             (int64_t)min(m0 + a_row + 32, A.M - 1) * ldx4,  (int64_t)min(m0 + a_row + 48, A.M - 1) * ldx4,
@@ -202,47 +246,30 @@ __global__ void __launch_bounds__(512, 2) k_linear_h3(const LinearH3Args P) {
     // lane (row fi, k half fh) of a 32-row fragment tile; 32-row offsets keep (row >> 1) & 7 == (fi >> 1) & 7
     const int sw = (fi >> 1) & 7;
     const int arow = (wm0 + fi) * HROW, brow = 2 * PIECE + (wn0 + fi) * HROW;
-    // The packed W pieces of a K step (2 pieces x 8 k blocks x 128 columns of 16 B = 8 words per thread) are
-    // copied global -> registers -> LDS by THESE waves, at the head of the step, requested one step ahead: the
-    // feeder waves are the ones short of issue slots (measured: feeder copying W too 5.0 k cycles per step,
-    // this split 3.6 k, the copy spread between the MFMA groups 4.5 k).  Unconditional loads + select, as
-    // in the feeder.
-    const int w_kb = tid >> 7, w_n = tid & 127;               // word (piece i >> 2, k block w_kb + 2 (i & 3), column w_n)
-    const int64_t wpiece = (int64_t)(P.Kp / 8) * A.N;         // 16-byte words per packed piece
-    const f16x8 *__restrict__ W8 = reinterpret_cast<const f16x8 *>(P.wp + HHDR);
-    const int w_col = min(n0 + w_n, A.N - 1), kbmax = (P.Kp >> 3) - 1;
-    f16x8 wb[8];
-    auto load_w = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int q = i >> 2, kb = kt * (HBK / 8) + w_kb + 2 * (i & 3);
-            const f16x8 v = W8[q * wpiece + (int64_t)min(kb, kbmax) * A.N + w_col];
-            f16x8 z;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
-            wb[i] = kb <= kbmax ? v : z;
-        }
-    };
-    auto store_w = [&](char *buf) {
+    // The W tile image of a K step (32 KB, contiguous in the packed weights) comes in by LDS-DMA: these waves
+    // issue its 32 x 1 KB pieces at the head of the step before the one that reads it -- no registers, no
+    // ds_write, no vector work -- and wait for their own pieces in front of the barrier that publishes the
+    // buffer.  (They issue no other vector-memory instruction, so the wait is exactly theirs; copying the
+    // tile through registers in these waves cost 1.5 k of a 3.6 k-cycle step.)
+    const char *wtiles = reinterpret_cast<const char *>(P.wp + HHDR) + (size_t)(tile % nb) * KT * H3_WTILE;
+    auto dma_w = [&](int kt, char *buf) {
+        const char *g = wtiles + (size_t)kt * H3_WTILE + wid * 8192 + lane * 16;
+        char *l = buf + 2 * PIECE + wid * 8192;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            *reinterpret_cast<f16x8 *>(buf + (2 + (i >> 2)) * PIECE + h3_off(w_n, w_kb + 2 * (i & 3))) = wb[i];
+            __builtin_amdgcn_global_load_lds((h3_glb_void *)(g + i * 1024), (h3_lds_void *)(l + i * 1024), 16, 0, 0);
     };
-    load_w(0);
-    store_w(smem_raw);
-    load_w(1 < KT ? 1 : 0);
+    dma_w(0, smem_raw);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();                                            // buffer 0 is complete
     H3_ST(0, sti);
     for (int kt = 0; kt < KT; ++kt) {
         const char *cur = smem_raw + (kt & 1) * H3_BUF;
-        if (kt + 1 < KT) {
-            store_w(smem_raw + ((kt & 1) ^ 1) * H3_BUF);      // free since the barrier that ended step kt - 1
-            load_w(kt + 2 < KT ? kt + 2 : kt + 1);
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        if (kt + 1 < KT) dma_w(kt + 1, smem_raw + ((kt & 1) ^ 1) * H3_BUF);   // free since the barrier that ended step kt - 1
+        // fragments of sub-step s + 1 are requested before the MFMAs of sub-step s are issued (two register sets)
+        f16x8 fa[2][TM][2], fb[2][TN][2];
+        auto read_frags = [&](int s, f16x8 (&a)[TM][2], f16x8 (&b)[TN][2]) {
             const int coff = ((2 * s + fh) ^ sw) << 4;
-            f16x8 a[TM][2], b[TN][2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
 #pragma unroll
@@ -252,6 +279,13 @@ __global__ void __launch_bounds__(512, 2) k_linear_h3(const LinearH3Args P) {
                 for (int j = 0; j < TN; ++j)
                     b[j][q] = *reinterpret_cast<const f16x8 *>(cur + brow + coff + q * PIECE + 32 * j * HROW);
             }
+        };
+        read_frags(0, fa[0], fb[0]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s + 1 < 4) read_frags(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+            f16x8 (&a)[TM][2] = fa[s & 1];
+            f16x8 (&b)[TN][2] = fb[s & 1];
             // term-major order: consecutive MFMAs write different accumulators
 #define H3_TERM(ACC, QA, QB)                                                                          \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)       \
@@ -262,6 +296,7 @@ __global__ void __launch_bounds__(512, 2) k_linear_h3(const LinearH3Args P) {
 #undef H3_TERM
         }
         H3_ST(0, sti);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next W tile have landed
         lds_barrier();       // buffer kt & 1 fully read (rewritten during step kt + 1), buffer (kt + 1) & 1 complete
         H3_ST(0, sti);
     }
@@ -294,6 +329,28 @@ static int launch_linear_h3(const LinearH3Args &P, hipStream_t s) {
 
 using namespace blgnn;
 
+extern "C" int64_t blgnn_packed_weight_h3g_elems(int32_t K, int32_t N) {
+    const int64_t KS = ((int64_t)K + HBK - 1) / HBK, NB = ((int64_t)N + 127) / 128;
+    return HHDR + NB * KS * (H3_WTILE / 2);               // fp16 elements
+}
+
+extern "C" int blgnn_pack_weight_h3g(const float *w, int64_t ldw, int32_t K, int32_t N, void *out, void *stream) {
+    BLGNN_CHECK_ARG(w && out && K > 0 && N > 0 && ldw >= N, "pack_weight_h3g: bad args");
+    BLGNN_CHECK_ARG(aligned16(out), "pack_weight_h3g: out must be 16-byte aligned");
+    const int KS = (K + HBK - 1) / HBK, NB = (N + 127) / 128;
+    hipStream_t s = (hipStream_t)stream;
+    // header word 1 is scratch for the absolute maximum (float bits), word 0 receives 1 / scale
+    unsigned *amax = reinterpret_cast<unsigned *>(out) + 1;
+    if (hipMemsetAsync(out, 0, HHDR * 2, s) != hipSuccess) return fail(BLGNN_ERR_LAUNCH, "pack_weight_h3g: memset failed");
+    const int64_t total = (int64_t)K * N;
+    hipLaunchKernelGGL(k_absmax_g, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)), dim3(256), 0, s,
+                       w, ldw, K, N, amax);
+    const int64_t words = (int64_t)NB * KS * 128 * 8;
+    hipLaunchKernelGGL(k_pack_h3g, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, w, ldw, K, N, KS, amax,
+                       reinterpret_cast<_Float16 *>(out));
+    return launch_status("pack_weight_h3g");
+}
+
 extern "C" int blgnn_row_absmax(const float *x, int64_t ldx, int32_t M, int32_t K, float *out, void *stream) {
     BLGNN_CHECK_ARG(M >= 0 && K > 0, "row_absmax: bad sizes");
     if (M == 0) return BLGNN_OK;
@@ -324,7 +381,7 @@ extern "C" int blgnn_linear_h3(const float *x, int64_t ldx, const float *row_ama
     A.vec_a = 1; A.vec_b = 0; A.amax_out = y_row_amax;
     P.wp = reinterpret_cast<const _Float16 *>(w_packed);
     P.row_amax = row_amax;
-    P.Kp = (K + 31) / 32 * 32;
+    P.KS = (K + HBK - 1) / HBK;
     hipStream_t s = (hipStream_t)stream;
     switch (act) {
         case BLGNN_ACT_RELU:    return launch_linear_h3<BLGNN_ACT_RELU>(P, s);

@@ -293,6 +293,13 @@ int blgnn_linear_x6(const float *x, int64_t ldx, const void *w_packed, float *y,
                     const float *act_param, const float *bn_scale,
                     const float *bn_shift, void *stream);
 
+/* W[K,N] fp32 -> the packed image blgnn_linear_h3 reads: a 16-byte header (inverse of the power-of-two
+ * scale that moves max |w| into [2^14, 2^15)) followed by ceil(N / 128) x ceil(K / 64) tile images of
+ * 32 KB, each laid out exactly as the kernel keeps a (column block, K step) in LDS, so a tile comes in
+ * by 32 linear LDS-DMA pieces.  `out` holds blgnn_packed_weight_h3g_elems(K, N) fp16 elements. */
+int64_t blgnn_packed_weight_h3g_elems(int32_t K, int32_t N);
+int blgnn_pack_weight_h3g(const float *w, int64_t ldw, int32_t K, int32_t N, void *out, void *stream);
+
 /* out[m] = max_k |x[m, k]|: the row magnitudes blgnn_linear_h3 normalises its X operand by.  A producer
  * that already knows them (it wrote the rows) may supply its own array instead. */
 int blgnn_row_absmax(const float *x, int64_t ldx, int32_t M, int32_t K, float *out, void *stream);
@@ -301,7 +308,7 @@ int blgnn_row_absmax(const float *x, int64_t ldx, int32_t M, int32_t K, float *o
  * normalised by exact powers of two -- X per row from row_amax[M], W as a whole when packed -- and
  * split in two fp16 pieces, three MFMAs per product, see blgnn_gin_layer_h3).  Same call sites as
  * blgnn_linear (the GMN propagator's f_message / f_node MLPs, model/layers_gmn.py:19-26,39-47, are
- * the large ones); w_packed = blgnn_pack_weight_h3(W[K,N]); row_amax[m] >= max_k |x[m, k]| (any
+ * the large ones); w_packed = blgnn_pack_weight_h3g(W[K,N]); row_amax[m] >= max_k |x[m, k]| (any
  * value within a factor 2 above the true maximum gives the same result).  y_row_amax (optional, [M],
  * ZERO-INITIALISED by the caller) receives max_n |y[m, n]| through atomic maxima from the column
  * tiles -- the row_amax of a following blgnn_linear_h3 on y, for free.  Needs K % 4 == 0,
