@@ -434,8 +434,8 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
         # every step so that the step's launches wait in the queue and the events bracket back-to-back
         # execution, not host launch latency.
         roofline = None
-        if want_roofline and rank == 0:
-            timer.enabled = True
+        if want_roofline:                       # every rank: eager steps contain the all-gather
+            timer.enabled = rank == 0
             blk = torch.empty(4096, 8192, device=device)
             blk_w = torch.empty(8192, 8192, device=device)
             for i in range(min(steps, 20)):

@@ -201,7 +201,7 @@ def make_synthetic(num_drugs, num_pairs, shape="drugbank", seed=20200614, device
     cards = DRUGCOMBO_CARDS if shape == "drugcombo" else FEATURE_CARDS
     codes = _atom_codes(rng, int(node_ptr[-1]), cards)
     x = one_hot_from_codes(codes, cards=cards, device=device)
-    store = MoleculeStore(x, edge_local, node_ptr, edge_ptr, range(num_drugs), device)
+    store = MoleculeStore(x, edge_local, node_ptr, edge_ptr, range(num_drugs), device, codes=codes, cards=cards)
     max_pairs = num_drugs * (num_drugs - 1) // 2
     pairs = _chung_lu_edges(rng, num_drugs, min(num_pairs, max_pairs))
     if num_edge_types > 1:

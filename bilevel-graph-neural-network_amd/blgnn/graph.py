@@ -39,6 +39,10 @@ class GraphData(object):
         self.num_graphs = num_graphs
         self._csr = None
         self._seg = None
+        # compact form of x when it is a concatenation of one-hot blocks: int8 [n, 8] value indices and the
+        # first column of every block (+ total width); the first lower layer can read these instead of x
+        self.codes = None
+        self.code_offsets = None
 
     @property
     def num_nodes(self):
@@ -103,7 +107,7 @@ class MoleculeStore(object):
     nx -> tensor conversion of src/batch.py:131-139 / model/layers_util.py:100-135;
     a batch is then a vectorised gather of slices."""
 
-    def __init__(self, x_all, edge_local, node_ptr, edge_ptr, gids, device):
+    def __init__(self, x_all, edge_local, node_ptr, edge_ptr, gids, device, codes=None, cards=None):
         """``x_all`` [A, F] node features of all molecules back to back (tensor or
         ndarray), ``edge_local`` int64 [2, E] per-molecule LOCAL node ids, symmetric and
         sorted by (row, col) within each molecule, ``node_ptr`` / ``edge_ptr`` the
@@ -118,6 +122,12 @@ class MoleculeStore(object):
         self.x = torch.as_tensor(x_all, dtype=torch.float32).to(self.device)
         self.edge_local = torch.as_tensor(edge_local, dtype=torch.int64).to(self.device)
         self.num_node_feat = int(self.x.shape[1])
+        self.codes, self.code_offsets = None, None
+        if codes is not None and cards is not None and len(cards) <= 8:
+            c = np.zeros((np.asarray(codes).shape[0], 8), dtype=np.int8)
+            c[:, :len(cards)] = np.asarray(codes, dtype=np.int8)
+            self.codes = torch.as_tensor(c).to(self.device)
+            self.code_offsets = [0] + np.cumsum([int(v) for v in cards]).tolist()
 
     @classmethod
     def from_lists(cls, xs, edge_indices, gids, device):
@@ -160,6 +170,9 @@ class MoleculeStore(object):
         batch = torch.as_tensor(g_of_node, device=dev)
         merged = GraphData(x=x, edge_index=ei, batch=batch, num_graphs=G)
         merged._seg = torch.as_tensor(node_off, dtype=torch.int32, device=dev)
+        if self.codes is not None:
+            merged.codes = self.codes.index_select(0, src_node_t)
+            merged.code_offsets = self.code_offsets
         ind_list = list(zip(node_off[:-1].tolist(), node_off[1:].tolist()))
         edge_ind_list = list(zip(edge_off[:-1].tolist(), edge_off[1:].tolist()))
         if unique_graphs:

@@ -115,7 +115,8 @@ def dataset_from_codes(gids, node_ptr, codes, cards, edge_ptr, edge_local, pairs
     """The compact on-disk / on-wire form (6 bytes per atom) -> BiGNNDataset; the one-hot expansion
     (utils/data/representation_node_feat.py:86-97) happens on the device."""
     x = one_hot_from_codes(np.asarray(codes, dtype=np.int64), cards=tuple(int(c) for c in cards), device=device)
-    store = MoleculeStore(x, np.asarray(edge_local, dtype=np.int64), node_ptr, edge_ptr, gids, device)
+    store = MoleculeStore(x, np.asarray(edge_local, dtype=np.int64), node_ptr, edge_ptr, gids, device,
+                          codes=np.asarray(codes), cards=[int(c) for c in cards])
     labels = np.ones(len(pairs), dtype=np.int64) if labels is None else np.asarray(labels)
     return BiGNNDataset(name, store, np.asarray(pairs, dtype=np.int64), labels,
                         multi_edge_types=len(np.unique(labels)) > 1)

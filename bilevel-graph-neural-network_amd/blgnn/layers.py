@@ -108,7 +108,19 @@ class NodeEmbedding(nn.Module):
                 w2 = self._cache.get("w2", lambda w: w.t().contiguous(), lin2.weight)
                 eps = self._cache.get("eps", lambda e: float(e[0]), self.conv.eps)
                 transform = getattr(FLAGS, "feature_transform", "bf16x6")
-                if transform == "f16x3" and ops.gin_layer_h3_supported(csr, ins, ins.shape[1], self.out_dim):
+                g = self._graph(batch_data)
+                codes = getattr(g, "codes", None) if ins is getattr(g, "x", None) else None
+                if transform == "f16x3" and getattr(FLAGS, "categorical_input", True) and \
+                        ops.gin_layer_h3_codes_supported(csr, codes, getattr(g, "code_offsets", None) or [0], self.out_dim) \
+                        and g.code_offsets[-1] == ins.shape[1]:
+                    # first lower layer on categorical features: 8 bytes of value indices per atom instead of the
+                    # one-hot row (utils/data/representation_node_feat.py:86-97), expanded inside the kernel
+                    w1p = self._cache.get("w1h", lambda w: ops.pack_weight_h3(w.t().contiguous()), lin1.weight)
+                    w2p = self._cache.get("w2h", lambda w: ops.pack_weight_h3(w.t().contiguous()), lin2.weight)
+                    x = ops.gin_layer_h3_codes(csr, codes, g.code_offsets, w1p, lin1.bias, w2p, lin2.bias,
+                                               self.out_dim, eps=eps, act=act, act_param=slopes, bn_scale=scale,
+                                               bn_shift=shift, out=out)
+                elif transform == "f16x3" and ops.gin_layer_h3_supported(csr, ins, ins.shape[1], self.out_dim):
                     # dense transforms on the fp16 matrix cores at fp32 accuracy (scaled two-piece split)
                     w1p = self._cache.get("w1h", lambda w: ops.pack_weight_h3(w.t().contiguous()), lin1.weight)
                     w2p = self._cache.get("w2h", lambda w: ops.pack_weight_h3(w.t().contiguous()), lin2.weight)

@@ -16,7 +16,7 @@ from .config import FLAGS
 __all__ = [
     "CSR", "csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear",
     "gat_conv", "gcn_conv", "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum", "row_absmax", "linear_writes_amax", "linear_h3_preferred",
-    "row_degree", "link_pred_head", "pack_weight_x6", "pack_weight_h3", "pack_weight_h3g", "gin_layer_h3", "gin_layer_h3_supported", "linear_x6_supported", "gin_layer_x6", "gin_layer_x6_supported", "gin_stack", "molecule_tiles", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
+    "row_degree", "link_pred_head", "pack_weight_x6", "pack_weight_h3", "pack_weight_h3g", "gin_layer_h3", "gin_layer_h3_supported", "gin_layer_h3_codes", "gin_layer_h3_codes_supported", "linear_x6_supported", "gin_layer_x6", "gin_layer_x6_supported", "gin_stack", "molecule_tiles", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
     "require_device",
 ]
 
@@ -194,6 +194,31 @@ def gin_layer_h3(csr, x, w1_packed, b1, w2_packed, b2, N, eps=0.0, act="identity
     call("blgnn_gin_layer_h3", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, xp, ldx, n, K,
          w1_packed.data_ptr(), _vec(b1, "b1"), w2_packed.data_ptr(), _vec(b2, "b2"), N, float(eps), _act(act),
          _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), yp, ldy, _stream())
+    return y
+
+
+def gin_layer_h3_codes_supported(csr, codes, offsets, N):
+    return (N == 128 and codes is not None and codes.dtype == torch.int8 and codes.dim() == 2 and codes.shape[1] == 8
+            and codes.is_contiguous() and len(offsets) - 1 <= 8 and offsets[-1] % 4 == 0 and offsets[-1] <= 64
+            and csr.nnz < 12 * max(csr.n, 1))
+
+
+def gin_layer_h3_codes(csr, codes, offsets, w1_packed, b1, w2_packed, b2, N, eps=0.0, act="identity", act_param=None,
+                       bn_scale=None, bn_shift=None, out=None):
+    """blgnn_gin_layer_h3 on categorical input: ``codes`` int8 [n, 8] (one value index per attribute),
+    ``offsets`` = first one-hot column of every attribute + the total width."""
+    import ctypes
+    require_device(codes, "codes")
+    n = codes.shape[0]
+    y = _out(out, n, N, w1_packed)
+    if y.dtype != torch.float32:
+        raise ValueError("blgnn: out must be float32")
+    yp, ldy = _mat(y, "out")
+    offs = (ctypes.c_int32 * len(offsets))(*[int(o) for o in offsets])
+    call("blgnn_gin_layer_h3_codes", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, codes.data_ptr(), offs,
+         len(offsets) - 1, n, w1_packed.data_ptr(), _vec(b1, "b1"), w2_packed.data_ptr(), _vec(b2, "b2"), N,
+         float(eps), _act(act), _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"),
+         yp, ldy, _stream())
     return y
 
 

@@ -66,7 +66,27 @@ struct GinH3Args {
     float self_coef;
     Epilogue epi;
     float *y; int64_t ldy;
+    // categorical input (first lower layer): 8 bytes per atom = one code per attribute (<= 8), expanded to the
+    // one-hot row of utils/data/representation_node_feat.py:86-97 on the fly; x / ldx unused then
+    const uint2 *codes;
+    uint8_t code_off[8];                     // first column of every attribute's one-hot block
+    int32_t n_attr;
 };
+
+// columns 4 l .. 4 l + 3 of the one-hot row of an atom
+__device__ __forceinline__ float4 onehot4(const uint2 c, const uint8_t (&off)[8], int n_attr, int l) {
+    float4 v = f4_zero();
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        if (a < n_attr) {
+            const unsigned code = ((a < 4 ? c.x : c.y) >> (8 * (a & 3))) & 0xffu;
+            const int rel = (int)off[a] + (int)code - 4 * l;
+            v.x = rel == 0 ? 1.f : v.x; v.y = rel == 1 ? 1.f : v.y;
+            v.z = rel == 2 ? 1.f : v.z; v.w = rel == 3 ? 1.f : v.w;
+        }
+    }
+    return v;
+}
 
 typedef __amdgpu_buffer_rsrc_t hrsrc_t;
 __device__ __forceinline__ hrsrc_t h3_rsrc(const _Float16 *Wp, int Kp, int N) {
@@ -127,7 +147,7 @@ __device__ __forceinline__ void gemm_h3(f32x16 (&acc0)[MT], f32x16 (&acc1)[MT], 
 
 // XBM rows per workgroup: 32 (four workgroups per CU) is what is launched; 64 (two per CU, every
 // weight fragment serves two row tiles) is kept as a template parameter only.
-template <int LG, int ACT, int XBM>
+template <int LG, int ACT, int XBM, bool CODES = false>
 __global__ void __launch_bounds__(256, XBM == 64 ? 2 : 4) k_gin_layer_h3(const GinH3Args A) {
     constexpr int N = 128, MT = XBM / 32;
     constexpr int RPW = WAVE / LG;
@@ -165,6 +185,10 @@ __global__ void __launch_bounds__(256, XBM == 64 ? 2 : 4) k_gin_layer_h3(const G
     const int64_t ldx4 = A.ldx >> 2;
     const int m0 = blockIdx.x * XBM;
     const bool vec_out = (A.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(A.y) & 15u) == 0);
+    auto load_x4 = [&](int row) -> float4 {                  // columns 4 l .. 4 l + 3 of feature row `row`
+        if (CODES) return onehot4(A.codes[row], A.code_off, A.n_attr, l);
+        return X[(int64_t)row * ldx4 + l];
+    };
 
     // ---- (0) requests: rowptr slice, feature rows, weight chunks, edge range -> column indices ---------------
     int rpv = 0;
@@ -176,7 +200,7 @@ __global__ void __launch_bounds__(256, XBM == 64 ? 2 : 4) k_gin_layer_h3(const G
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         const int row = m0 + (p * 4 + wid) * RPW + sub;
-        xin[p] = (ok && row < A.n) ? X[(int64_t)row * ldx4 + l] : f4_zero();
+        xin[p] = (ok && row < A.n) ? load_x4(row) : f4_zero();
     }
     f16x8 wfrag[HRING][2][2];
     h3_prefetch(wfrag, W1, A.Kp, lane_off);
@@ -247,7 +271,7 @@ __global__ void __launch_bounds__(256, XBM == 64 ? 2 : 4) k_gin_layer_h3(const G
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 fu[pp][q] = f4_zero();
-                if (far[pp][q] >= 0) fu[pp][q] = X[(int64_t)far[pp][q] * ldx4 + l];
+                if (far[pp][q] >= 0) fu[pp][q] = load_x4(far[pp][q]);
             }
 #pragma unroll
         for (int pp = 0; pp < FB; ++pp) {
@@ -260,7 +284,7 @@ __global__ void __launch_bounds__(256, XBM == 64 ? 2 : 4) k_gin_layer_h3(const G
                 const int first = cols_in_lds ? 4 : 0;
                 for (int e = e0 + first; e < e0 + cnt; ++e) {
                     const int jj = A.col[e];
-                    if (jj != row) f4_add(accv[pp], X[(int64_t)jj * ldx4 + l]);
+                    if (jj != row) f4_add(accv[pp], load_x4(jj));
                 }
             }
             // row maximum over the LG lanes of the row -> power-of-two scale
@@ -389,18 +413,18 @@ static size_t h3_lds_bytes(int K, int Kp, int XBM) {
     return r0 + r1 + sizeof(int) * (XBM + 4 + HCOLS) + sizeof(float) * 2 * XBM;
 }
 
-template <int LG, int ACT, int XBM>
+template <int LG, int ACT, int XBM, bool CODES = false>
 static int launch_h3_rows(const GinH3Args &A, hipStream_t s) {
     static size_t declared = 0;
     const size_t bytes = h3_lds_bytes(A.K, A.Kp, XBM);
     if (bytes > declared && bytes > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gin_layer_h3<LG, ACT, XBM>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gin_layer_h3<LG, ACT, XBM, CODES>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
             return fail(BLGNN_ERR_LAUNCH, "gin_layer_h3: cannot raise the dynamic LDS limit to %zu bytes", bytes);
         declared = bytes;
     }
     const int blocks = (A.n + XBM - 1) / XBM;
-    hipLaunchKernelGGL((k_gin_layer_h3<LG, ACT, XBM>), dim3(blocks), dim3(256), bytes, s, A);
+    hipLaunchKernelGGL((k_gin_layer_h3<LG, ACT, XBM, CODES>), dim3(blocks), dim3(256), bytes, s, A);
     return launch_status("gin_layer_h3");
 }
 
@@ -410,6 +434,20 @@ static int launch_h3(const GinH3Args &A, hipStream_t s) {
     // serving two row tiles -- measured the same on 471 k rows, 264 vs 259 us, and worse on graphs
     // that do not fill two rounds of them: 31.5 vs 24.3 us on 36 k rows.)
     return launch_h3_rows<LG, ACT, 32>(A, s);
+}
+
+// categorical input: 16 lanes x 4 columns cover the <= 64 one-hot columns of the first layer
+template <int ACT>
+static int launch_h3_codes(const GinH3Args &A, hipStream_t s) { return launch_h3_rows<16, ACT, 32, true>(A, s); }
+
+static int h3_codes_pick_act(const GinH3Args &A, hipStream_t s) {
+    switch (A.epi.act) {
+        case BLGNN_ACT_RELU:    return launch_h3_codes<BLGNN_ACT_RELU>(A, s);
+        case BLGNN_ACT_PRELU:   return launch_h3_codes<BLGNN_ACT_PRELU>(A, s);
+        case BLGNN_ACT_SIGMOID: return launch_h3_codes<BLGNN_ACT_SIGMOID>(A, s);
+        case BLGNN_ACT_TANH:    return launch_h3_codes<BLGNN_ACT_TANH>(A, s);
+        default:                return launch_h3_codes<BLGNN_ACT_IDENTITY>(A, s);
+    }
 }
 
 template <int LG>
@@ -470,8 +508,40 @@ extern "C" int blgnn_gin_layer_h3(const int32_t *rowptr, const int32_t *col, int
     A.b1 = b1; A.b2 = b2; A.self_coef = 1.f + eps;
     A.epi = Epilogue{b2, act_param, bn_scale, bn_shift, act};
     A.y = y; A.ldy = ldy;
+    A.codes = nullptr; A.n_attr = 0;
     hipStream_t s = (hipStream_t)stream;
     const int k4 = K / 4;
     if (k4 <= 16) return h3_pick_act<16>(A, s);
     return h3_pick_act<32>(A, s);
+}
+
+extern "C" int blgnn_gin_layer_h3_codes(const int32_t *rowptr, const int32_t *col, int64_t nnz, const void *codes,
+                                        const int32_t *code_offsets_host, int32_t num_attr, int32_t n,
+                                        const void *w1_packed, const float *b1, const void *w2_packed,
+                                        const float *b2, int32_t N, float eps, int32_t act, const float *act_param,
+                                        const float *bn_scale, const float *bn_shift, float *y, int64_t ldy,
+                                        void *stream) {
+    BLGNN_CHECK_ARG(n >= 0 && N > 0 && nnz >= 0 && num_attr >= 1 && num_attr <= 8 && code_offsets_host,
+                    "gin_layer_h3_codes: bad sizes");
+    if (n == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(rowptr && (col || nnz == 0) && codes && w1_packed && w2_packed && y, "gin_layer_h3_codes: null pointer");
+    const int K = code_offsets_host[num_attr];
+    BLGNN_CHECK_ARG(ldy >= N && act >= 0 && act <= BLGNN_ACT_TANH, "gin_layer_h3_codes: bad ldy / activation id");
+    if (N != 128 || K <= 0 || K > 64 || K % 4 != 0 || (reinterpret_cast<uintptr_t>(codes) & 7u) || !aligned16(w1_packed) ||
+        !aligned16(w2_packed))
+        return fail(BLGNN_ERR_UNSUPPORTED, "gin_layer_h3_codes: needs N == 128, one-hot width %% 4 == 0 and <= 64, 8-byte "
+                    "aligned codes (got N=%d width=%d)", N, K);
+    GinH3Args A;
+    A.rowptr = rowptr; A.col = col; A.x = nullptr; A.ldx = 0; A.n = n; A.K = K; A.Kp = (K + 31) / 32 * 32;
+    A.w1p = reinterpret_cast<const _Float16 *>(w1_packed); A.w2p = reinterpret_cast<const _Float16 *>(w2_packed);
+    A.b1 = b1; A.b2 = b2; A.self_coef = 1.f + eps;
+    A.epi = Epilogue{b2, act_param, bn_scale, bn_shift, act};
+    A.y = y; A.ldy = ldy;
+    A.codes = reinterpret_cast<const uint2 *>(codes); A.n_attr = num_attr;
+    for (int a = 0; a < 8; ++a) {
+        const int o = a < num_attr ? code_offsets_host[a] : 0;
+        BLGNN_CHECK_ARG(o >= 0 && o < 256, "gin_layer_h3_codes: attribute offset out of range");
+        A.code_off[a] = (uint8_t)o;
+    }
+    return h3_codes_pick_act(A, (hipStream_t)stream);
 }

@@ -150,6 +150,20 @@ int blgnn_gin_layer_h3(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                        const float *act_param, const float *bn_scale,
                        const float *bn_shift, float *y, int64_t ldy, void *stream);
 
+/* blgnn_gin_layer_h3 for the FIRST lower layer with categorical input: instead of the one-hot rows
+ * x[n, F_in] (utils/data/representation_node_feat.py:86-97: one block per attribute, one 1 per block)
+ * the kernel reads 8 bytes per atom -- codes[n][8], byte a = the value index of attribute a -- and
+ * expands them on the fly (6 bytes instead of 52 floats per atom on DrugBank).  code_offsets_host is a
+ * HOST array of num_attr + 1 ints: first column of every attribute's block, last = F_in (multiple of
+ * 4, <= 64).  Result identical to blgnn_gin_layer_h3 on the expanded rows. */
+int blgnn_gin_layer_h3_codes(const int32_t *rowptr, const int32_t *col, int64_t nnz,
+                             const void *codes, const int32_t *code_offsets_host,
+                             int32_t num_attr, int32_t n, const void *w1_packed,
+                             const float *b1, const void *w2_packed, const float *b2,
+                             int32_t N, float eps, int32_t act, const float *act_param,
+                             const float *bn_scale, const float *bn_shift, float *y,
+                             int64_t ldy, void *stream);
+
 /* The whole lower level in ONE launch: num_layers (<= 8) stacked GIN NodeEmbedding layers
  * (model/layers.py:26-31,51-57) + the node -> graph readout of every layer that is pooled
  * (model/layers_aggregation.py:27-42, multi-scale concat = one column slice per layer).

@@ -80,6 +80,10 @@ def linear_writes_amax(x, w_kn, transform=None):
     return False
 
 
+def gin_layer_h3_codes_supported(csr, codes, offsets, N):
+    return False
+
+
 def row_absmax(x, out=None):
     return x.abs().amax(dim=1)
 
@@ -175,6 +179,7 @@ def require_device(t, name="tensor"):
 
 
 NAMES = ["csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear", "linear_writes_amax", "row_absmax",
+         "gin_layer_h3_codes_supported",
          "gin_layer",
          "gin_layer_supported", "gin_layer_x6_supported", "gat_conv", "gcn_conv",
          "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum", "row_degree", "pair_gather_normalize", "link_pred_head",

@@ -158,6 +158,38 @@ def test_gin_layer_f16x3(device, K, act):
     assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + N:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("act", ["relu", "identity"])
+def test_gin_layer_f16x3_categorical_input(device, act):
+    """first lower layer fed with 8 bytes of attribute value indices per atom == the same layer fed with the
+    one-hot rows those indices stand for (bit for bit: same arithmetic) == oracle"""
+    from blgnn.dataset import FEATURE_CARDS, one_hot_from_codes
+    N = 128
+    ei, _, n = molecule_graph(41, 21)
+    rng = np.random.default_rng(7)
+    codes6 = np.stack([rng.integers(0, c, size=n) for c in FEATURE_CARDS], axis=1)
+    x = one_hot_from_codes(codes6, device="cpu")
+    K = x.shape[1]
+    codes = np.zeros((n, 8), dtype=np.int8)
+    codes[:, :6] = codes6
+    offsets = [0] + np.cumsum(FEATURE_CARDS).tolist()
+    g = torch.Generator().manual_seed(3)
+    w1, b1 = torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g) * 0.1
+    w2, b2 = torch.randn(N, N, generator=g) / N ** 0.5, torch.randn(N, generator=g) * 0.1
+    scale, shift = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    D = lambda t: t.double()
+    ref = oracle.apply_act(oracle.gin_conv(D(x), ei, D(w1), D(b1), D(w2), D(b2), act, eps=0.1), act) * D(scale) + D(shift)
+    dv = lambda t: t.to(device)
+    csr = ops.csr_from_edge_index(dv(ei), n)
+    cd = torch.as_tensor(codes).to(device)
+    assert ops.gin_layer_h3_codes_supported(csr, cd, offsets, N)
+    w1p, w2p = ops.pack_weight_h3(dv(w1.t().contiguous())), ops.pack_weight_h3(dv(w2.t().contiguous()))
+    a = ops.gin_layer_h3(csr, dv(x), w1p, dv(b1), w2p, dv(b2), N, eps=0.1, act=act, bn_scale=dv(scale), bn_shift=dv(shift))
+    b = ops.gin_layer_h3_codes(csr, cd, offsets, w1p, dv(b1), w2p, dv(b2), N, eps=0.1, act=act, bn_scale=dv(scale),
+                               bn_shift=dv(shift))
+    assert torch.equal(a, b)
+    assert max_err(b, ref) < TOL
+
+
 @pytest.mark.parametrize("xs,ws", [(1e-6, 1.0), (3e4, 1.0), (1.0, 1e-5), (1.0, 300.0), (1e5, 1e-4)])
 def test_gin_layer_f16x3_range(device, xs, ws):
     """the power-of-two normalisation keeps the fp16 pieces in range for tiny / huge activations and weights,
