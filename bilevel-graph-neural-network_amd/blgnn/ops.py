@@ -180,7 +180,7 @@ def pack_weight_h3g(w_kn):
 
 
 def gin_layer_h3_supported(csr, x, K, N):
-    return (N == 128 and K % 4 == 0 and K <= 128 and x.stride(0) % 4 == 0
+    return (N in (128, 256) and K % 4 == 0 and K <= N and x.stride(0) % 4 == 0
             and x.data_ptr() % 16 == 0 and csr.nnz < 12 * max(csr.n, 1))
 
 

@@ -89,15 +89,15 @@ __device__ __forceinline__ float4 onehot4(const uint2 c, const uint8_t (&off)[8]
 }
 
 typedef __amdgpu_buffer_rsrc_t hrsrc_t;
-__device__ __forceinline__ hrsrc_t h3_rsrc(const _Float16 *Wp, int Kp, int N) {
+__device__ __forceinline__ hrsrc_t h3_rsrc(const _Float16 *Wp, int Kp, int N) {   // N = packed row width
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(Wp), 0, HHDR * 2 + 2 * Kp * N * 2, 0x00020000);
 }
 
 // Weight fragments of one 32-deep chunk: [step][piece].  Lane (fi, fh) holds the 8 consecutive k of
 // output column n_base + fi (the MFMA A operand).  Buffer addressing: one per-lane VGPR offset +
 // a wave-uniform SGPR offset per load.
+template <int N>
 __device__ __forceinline__ void load_b_h3(f16x8 (&dst)[2][2], hrsrc_t W, int Kp, int kc, unsigned lane_off) {
-    constexpr int N = 128;
     const unsigned piece = (unsigned)Kp * N * 2u;                 // bytes
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -111,15 +111,16 @@ __device__ __forceinline__ void load_b_h3(f16x8 (&dst)[2][2], hrsrc_t W, int Kp,
 
 constexpr int HRING = 3;         // weight chunk buffers (16 VGPRs each), two chunks ahead of the MFMAs
 
+template <int N>
 __device__ __forceinline__ void h3_prefetch(f16x8 (&w)[HRING][2][2], hrsrc_t Wp, int Kp, unsigned lane_off) {
 #pragma unroll
     for (int u = 0; u < HRING - 1; ++u)
-        if (u * KC < Kp) load_b_h3(w[u], Wp, Kp, u * KC, lane_off);
+        if (u * KC < Kp) load_b_h3<N>(w[u], Wp, Kp, u * KC, lane_off);
 }
 
 // acc0 += w1.a1 ; acc1 += w1.a2 + w2.a1, for both 32-row halves of the tile (transposed GEMM: the
 // lane ends up with n = n_base + 8 (r >> 2) + 4 fh + (r & 3), m = 32 mt + fi)
-template <int MT>
+template <int MT, int N>
 __device__ __forceinline__ void gemm_h3(f32x16 (&acc0)[MT], f32x16 (&acc1)[MT], const char *Ap, int sa, hrsrc_t Wp,
                                         int Kp, unsigned lane_off, int fi, int fh, f16x8 (&w)[HRING][2][2]) {
     const int piece_bytes = MT * 32 * sa;
@@ -129,7 +130,7 @@ __device__ __forceinline__ void gemm_h3(f32x16 (&acc0)[MT], f32x16 (&acc1)[MT], 
         for (int u = 0; u < HRING; ++u) {
             const int k = kc + u * KC;
             if (k < Kp) {
-                if (k + (HRING - 1) * KC < Kp) load_b_h3(w[(u + HRING - 1) % HRING], Wp, Kp, k + (HRING - 1) * KC, lane_off);
+                if (k + (HRING - 1) * KC < Kp) load_b_h3<N>(w[(u + HRING - 1) % HRING], Wp, Kp, k + (HRING - 1) * KC, lane_off);
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -145,16 +146,20 @@ __device__ __forceinline__ void gemm_h3(f32x16 (&acc0)[MT], f32x16 (&acc1)[MT], 
     }
 }
 
-// XBM rows per workgroup: 32 (four workgroups per CU) is what is launched; 64 (two per CU, every
-// weight fragment serves two row tiles) is kept as a template parameter only.
-template <int LG, int ACT, int XBM, bool CODES = false>
-__global__ void __launch_bounds__(256, XBM == 64 ? 2 : 4) k_gin_layer_h3(const GinH3Args A) {
-    constexpr int N = 128, MT = XBM / 32;
+// Two shapes are launched.  N = 128: XBM = 32 rows per 256-thread workgroup, four workgroups per CU.
+// N = 256 (K <= 256): XBM = 64 rows per 512-thread workgroup (NW = 8 waves, one 32-column group each), one
+// workgroup per CU: every weight fragment serves two row tiles, i.e. 8.2 KB of weight traffic per row
+// against 24.6 KB for the bf16x6 kernel's 32-row tiles -- at d = 256 that traffic (L2 -> CU operand
+// delivery, ~18 B/clk/CU), not the matrix cores, sets the time of these layers.
+template <int LG, int ACT, int XBM, bool CODES = false, int N = 128>
+__global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_layer_h3(const GinH3Args A) {
+    constexpr int MT = XBM / 32;
+    constexpr int NW = N / 32, NTH = 64 * NW;               // waves / threads per workgroup
     constexpr int RPW = WAVE / LG;
-    constexpr int PASSES = XBM / (4 * RPW);
+    constexpr int PASSES = XBM / (NW * RPW);
     constexpr int LDO = N + 4;
     constexpr int SH = N * 2 + 16;                  // hidden piece row stride (bytes)
-    constexpr int NCV = HCOLS / 256;
+    constexpr int NCV = (HCOLS + NTH - 1) / NTH;
     constexpr int N4 = N / 4;
     extern __shared__ float4 lds4[];
     char *lds = reinterpret_cast<char *>(lds4);
@@ -199,11 +204,11 @@ __global__ void __launch_bounds__(256, XBM == 64 ? 2 : 4) k_gin_layer_h3(const G
     float4 xin[PASSES];
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
-        const int row = m0 + (p * 4 + wid) * RPW + sub;
+        const int row = m0 + (p * NW + wid) * RPW + sub;
         xin[p] = (ok && row < A.n) ? load_x4(row) : f4_zero();
     }
     f16x8 wfrag[HRING][2][2];
-    h3_prefetch(wfrag, W1, A.Kp, lane_off);
+    h3_prefetch<N>(wfrag, W1, A.Kp, lane_off);
     const float w1inv = *reinterpret_cast<const float *>(A.w1p), w2inv = *reinterpret_cast<const float *>(A.w2p);
     const int e_lo = A.rowptr[m0];                                   // uniform addresses: scalar loads
     const int ncol_all = A.rowptr[m0 + XBM < A.n ? m0 + XBM : A.n] - e_lo;
@@ -211,23 +216,23 @@ __global__ void __launch_bounds__(256, XBM == 64 ? 2 : 4) k_gin_layer_h3(const G
     int cv[NCV];
 #pragma unroll
     for (int i = 0; i < NCV; ++i) {
-        const int idx = threadIdx.x + 256 * i;
+        const int idx = threadIdx.x + NTH * i;
         cv[i] = (cols_in_lds && idx < ncol_all) ? A.col[e_lo + idx] : 0;
     }
     if (threadIdx.x <= XBM) rp[threadIdx.x] = rpv;
     if (threadIdx.x < XBM) hmax[threadIdx.x] = 0u;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
-        const int m = (p * 4 + wid) * RPW + sub;
+        const int m = (p * NW + wid) * RPW + sub;
         if (ok) *reinterpret_cast<float4 *>(Xs + m * A.K + 4 * l) = xin[p];
     }
 #pragma unroll
     for (int i = 0; i < NCV; ++i) {
-        const int idx = threadIdx.x + 256 * i;
+        const int idx = threadIdx.x + NTH * i;
         if (cols_in_lds && idx < ncol_all) cs[idx] = cv[i];
     }
     // zero the K padding columns of the two aggregated pieces
-    for (int idx = threadIdx.x; idx < 2 * XBM * (A.Kp - A.K); idx += 256) {
+    for (int idx = threadIdx.x; idx < 2 * XBM * (A.Kp - A.K); idx += NTH) {
         const int per = XBM * (A.Kp - A.K);
         const int q = idx / per, rem = idx - q * per;
         const int m = rem / (A.Kp - A.K), k = A.K + rem % (A.Kp - A.K);
@@ -244,7 +249,7 @@ __global__ void __launch_bounds__(256, XBM == 64 ? 2 : 4) k_gin_layer_h3(const G
         int far[FB][4];
 #pragma unroll
         for (int pp = 0; pp < FB; ++pp) {
-            const int m = ((pg + pp) * 4 + wid) * RPW + sub;
+            const int m = ((pg + pp) * NW + wid) * RPW + sub;
             const int row = m0 + m;
             const int e0 = rp[m], cnt = rp[m + 1] - e0;
             const int lo4 = ok ? 4 * l : 0;
@@ -275,7 +280,7 @@ __global__ void __launch_bounds__(256, XBM == 64 ? 2 : 4) k_gin_layer_h3(const G
             }
 #pragma unroll
         for (int pp = 0; pp < FB; ++pp) {
-            const int m = ((pg + pp) * 4 + wid) * RPW + sub;
+            const int m = ((pg + pp) * NW + wid) * RPW + sub;
             const int row = m0 + m;
 #pragma unroll
             for (int q = 0; q < 4; ++q) f4_add(accv[pp], fu[pp][q]);
@@ -323,8 +328,8 @@ __global__ void __launch_bounds__(256, XBM == 64 ? 2 : 4) k_gin_layer_h3(const G
         psl[g] = (ACT == BLGNN_ACT_PRELU && A.epi.act_param) ? *reinterpret_cast<const float4 *>(A.epi.act_param + c)
                                                             : f4_zero();
     }
-    gemm_h3<MT>(acc0, acc1, Ap, sa, W1, A.Kp, lane_off, fi, fh, wfrag);
-    h3_prefetch(wfrag, W2, N, lane_off);
+    gemm_h3<MT, N>(acc0, acc1, Ap, sa, W1, A.Kp, lane_off, fi, fh, wfrag);
+    h3_prefetch<N>(wfrag, W2, N, lane_off);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const float rs = ainv[mt * 32 + fi] * w1inv;
@@ -373,7 +378,7 @@ __global__ void __launch_bounds__(256, XBM == 64 ? 2 : 4) k_gin_layer_h3(const G
         if (A.epi.bn_scale) psc[g] = *reinterpret_cast<const float4 *>(A.epi.bn_scale + c);
         if (A.epi.bn_scale && A.epi.bn_shift) psh[g] = *reinterpret_cast<const float4 *>(A.epi.bn_shift + c);
     }
-    gemm_h3<MT>(acc0, acc1, Hp, SH, W2, N, lane_off, fi, fh, wfrag);
+    gemm_h3<MT, N>(acc0, acc1, Hp, SH, W2, N, lane_off, fi, fh, wfrag);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const float rs = hinv[mt] * w2inv;
@@ -393,7 +398,7 @@ __global__ void __launch_bounds__(256, XBM == 64 ? 2 : 4) k_gin_layer_h3(const G
         }
     }
     lds_barrier();
-    for (int idx = threadIdx.x; idx < XBM * N4; idx += 256) {
+    for (int idx = threadIdx.x; idx < XBM * N4; idx += NTH) {
         const int m = idx / N4, c4 = idx % N4;
         const int row = m0 + m;
         if (row >= A.n) continue;
@@ -404,8 +409,7 @@ __global__ void __launch_bounds__(256, XBM == 64 ? 2 : 4) k_gin_layer_h3(const G
     }
 }
 
-static size_t h3_lds_bytes(int K, int Kp, int XBM) {
-    const int N = 128;
+static size_t h3_lds_bytes(int K, int Kp, int XBM, int N = 128) {
     size_t r0 = (size_t)2 * XBM * (Kp * 2 + 16);
     if ((size_t)XBM * (N + 4) * 4 > r0) r0 = (size_t)XBM * (N + 4) * 4;
     size_t r1 = (size_t)XBM * K * 4;
@@ -413,18 +417,18 @@ static size_t h3_lds_bytes(int K, int Kp, int XBM) {
     return r0 + r1 + sizeof(int) * (XBM + 4 + HCOLS) + sizeof(float) * 2 * XBM;
 }
 
-template <int LG, int ACT, int XBM, bool CODES = false>
+template <int LG, int ACT, int XBM, bool CODES = false, int N = 128>
 static int launch_h3_rows(const GinH3Args &A, hipStream_t s) {
     static size_t declared = 0;
-    const size_t bytes = h3_lds_bytes(A.K, A.Kp, XBM);
+    const size_t bytes = h3_lds_bytes(A.K, A.Kp, XBM, N);
     if (bytes > declared && bytes > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gin_layer_h3<LG, ACT, XBM, CODES>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gin_layer_h3<LG, ACT, XBM, CODES, N>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
             return fail(BLGNN_ERR_LAUNCH, "gin_layer_h3: cannot raise the dynamic LDS limit to %zu bytes", bytes);
         declared = bytes;
     }
     const int blocks = (A.n + XBM - 1) / XBM;
-    hipLaunchKernelGGL((k_gin_layer_h3<LG, ACT, XBM, CODES>), dim3(blocks), dim3(256), bytes, s, A);
+    hipLaunchKernelGGL((k_gin_layer_h3<LG, ACT, XBM, CODES, N>), dim3(blocks), dim3(N * 2), bytes, s, A);
     return launch_status("gin_layer_h3");
 }
 
@@ -447,6 +451,18 @@ static int h3_codes_pick_act(const GinH3Args &A, hipStream_t s) {
         case BLGNN_ACT_SIGMOID: return launch_h3_codes<BLGNN_ACT_SIGMOID>(A, s);
         case BLGNN_ACT_TANH:    return launch_h3_codes<BLGNN_ACT_TANH>(A, s);
         default:                return launch_h3_codes<BLGNN_ACT_IDENTITY>(A, s);
+    }
+}
+
+// N = 256: 64-row tiles, 512 threads
+template <int LG>
+static int h3w_pick_act(const GinH3Args &A, hipStream_t s) {
+    switch (A.epi.act) {
+        case BLGNN_ACT_RELU:    return launch_h3_rows<LG, BLGNN_ACT_RELU, 64, false, 256>(A, s);
+        case BLGNN_ACT_PRELU:   return launch_h3_rows<LG, BLGNN_ACT_PRELU, 64, false, 256>(A, s);
+        case BLGNN_ACT_SIGMOID: return launch_h3_rows<LG, BLGNN_ACT_SIGMOID, 64, false, 256>(A, s);
+        case BLGNN_ACT_TANH:    return launch_h3_rows<LG, BLGNN_ACT_TANH, 64, false, 256>(A, s);
+        default:                return launch_h3_rows<LG, BLGNN_ACT_IDENTITY, 64, false, 256>(A, s);
     }
 }
 
@@ -498,9 +514,9 @@ extern "C" int blgnn_gin_layer_h3(const int32_t *rowptr, const int32_t *col, int
     BLGNN_CHECK_ARG(ldx >= K && ldy >= N, "gin_layer_h3: leading dimension too small");
     BLGNN_CHECK_ARG(act >= 0 && act <= BLGNN_ACT_TANH, "gin_layer_h3: bad activation id");
     BLGNN_CHECK_ARG(x != y, "gin_layer_h3: x and y must not alias");
-    if (N != 128 || K % 4 != 0 || K > 128 || ldx % 4 != 0 || !aligned16(x) || !aligned16(w1_packed) ||
+    if (!(N == 128 || N == 256) || K % 4 != 0 || K > N || ldx % 4 != 0 || !aligned16(x) || !aligned16(w1_packed) ||
         !aligned16(w2_packed))
-        return fail(BLGNN_ERR_UNSUPPORTED, "gin_layer_h3: needs N == 128, K %% 4 == 0, K <= 128 and 16-byte aligned x / "
+        return fail(BLGNN_ERR_UNSUPPORTED, "gin_layer_h3: needs N in {128, 256}, K %% 4 == 0, K <= N and 16-byte aligned x / "
                     "packed weights (got N=%d K=%d); use blgnn_gin_layer_x6", N, K);
     GinH3Args A;
     A.rowptr = rowptr; A.col = col; A.x = x; A.ldx = ldx; A.n = n; A.K = K; A.Kp = (K + 31) / 32 * 32;
@@ -511,6 +527,11 @@ extern "C" int blgnn_gin_layer_h3(const int32_t *rowptr, const int32_t *col, int
     A.codes = nullptr; A.n_attr = 0;
     hipStream_t s = (hipStream_t)stream;
     const int k4 = K / 4;
+    if (N == 256) {
+        if (k4 <= 16) return h3w_pick_act<16>(A, s);
+        if (k4 <= 32) return h3w_pick_act<32>(A, s);
+        return h3w_pick_act<64>(A, s);
+    }
     if (k4 <= 16) return h3_pick_act<16>(A, s);
     return h3_pick_act<32>(A, s);
 }

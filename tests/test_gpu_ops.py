@@ -134,10 +134,12 @@ def test_linear_epilogue(device, act):
     assert max_err(got, ref) < TOL
 
 
-@pytest.mark.parametrize("K,act", [(52, "relu"), (128, "relu"), (128, "identity"), (64, "prelu"), (40, "tanh"), (128, "sigmoid")])
-def test_gin_layer_f16x3(device, K, act):
-    """fp16 two-piece split GIN layer (64-row tiles, row / matrix power-of-two scaling) == oracle at the fp32 bar"""
-    N = 128
+@pytest.mark.parametrize("K,act,N", [(52, "relu", 128), (128, "relu", 128), (128, "identity", 128), (64, "prelu", 128),
+                                     (40, "tanh", 128), (128, "sigmoid", 128), (52, "relu", 256), (256, "relu", 256),
+                                     (256, "identity", 256), (128, "prelu", 256), (100, "tanh", 256)])
+def test_gin_layer_f16x3(device, K, act, N):
+    """fp16 two-piece split GIN layer (row / matrix power-of-two scaling; N = 128: 32-row tiles, N = 256: 64-row
+    tiles of a 512-thread workgroup) == oracle at the fp32 bar"""
     ei, _, n = molecule_graph(53, 21)                       # n is not a multiple of the 64-row tile
     g = torch.Generator().manual_seed(K * 7 + len(act))
     x = torch.randn(n, K, generator=g)
