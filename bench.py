@@ -410,7 +410,7 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
                            use_graph=not args.no_graph, overlap=not args.no_overlap,
                            fuse_lower=(False if args.no_fuse_lower else (True if args.fuse_lower else None)),
                            readout_with_upper=args.readout_with_upper,
-                           lower_cus_per_xcd=lower_cus)
+                           lower_cus_per_xcd=lower_cus, exchange_transformed=(True if emu else None))
     try:
         engine.capture()
         # a fresh random batch of pair ids every step (src/sampler.py:120-131), drawn ahead of the timed
@@ -457,6 +457,8 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
                       "hip_graph": bool(engine.use_graph), "two_stream_overlap": bool(engine.overlap),
                       "readout_with_upper": bool(engine.readout_with_upper),
                       "lower_cus_per_xcd": engine.lower_cus_per_xcd, "fused_lower_stack": engine.fused is not None,
+                      "exchange": ("first interaction layer's transform of the pooled rows [N_r, d+2]"
+                                   if engine.exchange_transformed else "pooled rows [N_r, D_pool]"),
                       "parallelism": "molecule shards x%d + all-gather(pooled) + pair shards" % world}}
     if want_roofline and rank == 0:
         ms, work, names = timer.result()

@@ -133,7 +133,8 @@ class BiLevelEngine(object):
     ``step(pairs)`` with an int array ``[B, 2]`` of graph ids scores those pairs."""
 
     def __init__(self, model, lower_batch, upper_batches, graph, sharded=None, world_size=1,
-                 use_graph=True, overlap=True, fuse_lower=None, readout_with_upper=None, lower_cus_per_xcd=None):
+                 use_graph=True, overlap=True, fuse_lower=None, readout_with_upper=None, lower_cus_per_xcd=None,
+                 exchange_transformed=None):
         from .config import FLAGS
         k = FLAGS.last_lower_lyr_num
         self.model = model
@@ -210,14 +211,31 @@ class BiLevelEngine(object):
                 self._masked = pair
                 self.stream_l, self.stream_u = pair.first, pair.second
                 self.lower_cus_per_xcd = pair.cus
+        # What crosses the wire.  Default with N > 1 and a GAT first interaction layer: the rank applies that
+        # layer's ROW-WISE half (h = pooled @ W, both attention scores) to its own pooled rows and the all-gather
+        # carries [N_r, d + 2] instead of [N_r, D_pool] (5x fewer bytes with a five-scale readout), and the
+        # D_pool-wide GEMM is no longer replicated on every rank.  Same kernels on the same rows: the scores are
+        # bit for bit those of the replicated evaluation (``exchange_transformed=True`` at one rank runs this
+        # path without a collective: tests/test_gpu_model.py).
+        first = self.upper_layers[1] if len(self.upper_layers) > 2 else None
+        can = (isinstance(first, NodeEmbedding) and first.type == 'gat' and first.higher_level
+               and not self.readout_with_upper)
+        if exchange_transformed is None:
+            exchange_transformed = self.world > 1
+        self.exchange_transformed = bool(exchange_transformed and can)
+        self.h_full = [None] * self.parities
         # exchange buffers (N > 1): padded send block, gathered blocks, row index that undoes the padding
         self._xchg = None
-        if self.world > 1:
-            counts = [int(c) for c in sharded.counts]
-            cmax, D = max(counts), base.shape[1]
+        if self.world > 1 or self.exchange_transformed:
+            counts = [int(c) for c in sharded.counts] if self.world > 1 else [self.local_hi - self.local_lo]
+            cmax = max(counts)
+            D = first.out_dim + 4 if self.exchange_transformed else base.shape[1]
+            if self.exchange_transformed:
+                n_all = base.shape[0]
+                self.h_full = [torch.zeros((n_all, D), dtype=torch.float32, device=dev) for _ in range(self.parities)]
             src = np.concatenate([r * cmax + np.arange(c, dtype=np.int64) for r, c in enumerate(counts)])
             self._xchg = {"send": [torch.zeros((cmax, D), dtype=torch.float32, device=dev) for _ in range(self.parities)],
-                          "recv": [torch.empty((self.world * cmax, D), dtype=torch.float32, device=dev)
+                          "recv": [torch.empty((len(counts) * cmax, D), dtype=torch.float32, device=dev)
                                    for _ in range(self.parities)],
                           "rows": torch.as_tensor(src).to(dev), "even": all(c == cmax for c in counts)}
         # Pinned-memory copies leave events of torch's host allocator on the stream they ran on; those must
@@ -266,36 +284,53 @@ class BiLevelEngine(object):
 
     # ---- the three pieces of one forward -------------------------------------------------
     def lower(self, parity=0, readout=True):
-        """-> this rank's pooled rows (a view of init_x: local drugs are a contiguous row range).
-        ``readout=False`` stops before the node -> graph readout and keeps the activations for
-        ``upper(..., readout=True)``."""
+        """-> what this rank contributes to the exchange: its pooled rows (a view of init_x: local drugs are a
+        contiguous row range), or -- ``exchange_transformed`` -- the send block holding the first interaction
+        layer's transform of those rows.  ``readout=False`` stops before the node -> graph readout and keeps
+        the activations for ``upper(..., readout=True)``."""
         self.graph.init_x = self.init_x[parity]
         if self.fused is not None:
             self.fused.run(self.model, self.init_x[parity])
-            return self.init_x[parity][self.local_lo:self.local_hi]
-        with torch.no_grad():
-            m = self.model
-            m.acts = [self.lower_batch.merge_data['merge'].x]
-            for layer in (self.lower_layers if readout else self.lower_layers[:-1]):
-                m.acts.append(layer(m.acts[-1], self.lower_batch, m))
-            if not readout:
-                self.lower_acts[parity] = list(m.acts)
-            return self.init_x[parity][self.local_lo:self.local_hi]
+        else:
+            with torch.no_grad():
+                m = self.model
+                m.acts = [self.lower_batch.merge_data['merge'].x]
+                for layer in (self.lower_layers if readout else self.lower_layers[:-1]):
+                    m.acts.append(layer(m.acts[-1], self.lower_batch, m))
+                if not readout:
+                    self.lower_acts[parity] = list(m.acts)
+        pooled = self.init_x[parity][self.local_lo:self.local_hi]
+        if not self.exchange_transformed:
+            return pooled
+        first = self.upper_layers[1]
+        d = first.out_dim
+        send = self._xchg["send"][parity]
+        rows = pooled.shape[0]
+        _, sc = first.gat_transform_rows(pooled, h=send[:rows, :d])
+        send[:rows, d:d + 2].copy_(sc.t())                     # the two scores ride in columns d, d + 1
+        return send[:rows]
 
     def exchange(self, pooled, parity=0):
         """The one collective of the path: all-gather of the pooled drug rows (padded to the largest
         shard) into persistent buffers, then ONE row gather that drops the padding into init_x."""
-        if self.world <= 1:
+        if self.world <= 1 and not self.exchange_transformed:
             return
-        import torch.distributed as dist
         x = self._xchg
         send, recv = x["send"][parity], x["recv"][parity]
-        send[:pooled.shape[0]].copy_(pooled)
-        dist.all_gather_into_tensor(recv, send, group=self.sharded.group)
+        dest = self.h_full[parity] if self.exchange_transformed else self.init_x[parity]
+        if not self.exchange_transformed:
+            send[:pooled.shape[0]].copy_(pooled)               # (transformed rows were written into ``send``)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(recv, send, group=self.sharded.group)
+        else:                                                  # one rank (tests, --emulate-world): its own rows only
+            n = self.local_hi - self.local_lo
+            dest[self.local_lo:self.local_hi].copy_(send[:n])
+            return
         if x["even"]:
-            self.init_x[parity].copy_(recv)
+            dest.copy_(recv)
         else:
-            torch.index_select(recv, 0, x["rows"], out=self.init_x[parity])
+            torch.index_select(recv, 0, x["rows"], out=dest)
 
     def upper(self, parity=0, readout=False):
         """Interaction-level layers + pair scorer on the rows in ``ids_dev[parity]``."""
@@ -307,7 +342,17 @@ class BiLevelEngine(object):
                 self.lower_layers[-1](m.acts[-1], self.lower_batch, m)
             b._pair_row_ids = (self.ids_dev[parity][0], self.ids_dev[parity][1])
             m.acts = [b.merge_data['merge'].x]
-            for layer in self.upper_layers:
+            layers = self.upper_layers
+            if self.exchange_transformed:
+                # LoadInteraction (builds / caches the interaction CSR), then the first GAT layer's graph half on
+                # the gathered table [N, d | s_dst s_src]
+                m.acts.append(layers[0](m.acts[-1], b, m))
+                first, hf = layers[1], self.h_full[parity]
+                d = first.out_dim
+                sc = hf[:, d:d + 2].t().contiguous()
+                m.acts.append(first.gat_forward_from_transform(hf[:, :d], sc, b, m))
+                layers = layers[2:]
+            for layer in layers:
                 m.acts.append(layer(m.acts[-1], b, m))
             return m.acts[-1]
 

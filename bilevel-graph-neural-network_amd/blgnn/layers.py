@@ -158,6 +158,30 @@ class NodeEmbedding(nn.Module):
         return x
 
 
+    # ---- GAT split at its row-wise / graph-wise seam (multi-GPU: blgnn/engine.py) -------------------------
+    def gat_transform_rows(self, x, h=None):
+        """Row-wise half of a GAT layer on any subset of rows: -> (h, scores [2, rows])."""
+        assert self.type == 'gat'
+        with torch.no_grad():
+            return ops.gat_transform(x, self.conv.weight, self.conv.att, h=h)
+
+    def gat_forward_from_transform(self, h, sc, batch_data, model, out=None):
+        """Graph half of the layer on the full transformed table; same result as ``forward`` on the rows
+        the table was transformed from."""
+        assert self.type == 'gat'
+        csr = self._graph(batch_data).csr()
+        slopes = prelu_slopes(self._cache, "prelu", self.act, self.out_dim)
+        scale, shift = bn_affine(self._cache, "bn", self.bn)
+        with torch.no_grad():
+            x = ops.gat_from_transform(csr, h, sc, self.conv.bias, group=getattr(FLAGS, "gat_softmax_group", "src"),
+                                       slope=self.conv.negative_slope, act=act_name(self.act), act_param=slopes,
+                                       bn_scale=scale, bn_shift=shift, out=out)
+            model.store_layer_output(self, x)
+            if self.normalize:
+                x = ops.l2_normalize_rows(x)
+        return x
+
+
 class Loss(nn.Module):
     """model/layers.py:66-89.  After the hot path; plain torch (SURVEY section 2 #1)."""
 

@@ -15,7 +15,7 @@ from .config import FLAGS
 
 __all__ = [
     "CSR", "csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear",
-    "gat_conv", "gcn_conv", "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum", "row_absmax", "linear_writes_amax", "linear_h3_preferred",
+    "gat_conv", "gat_transform", "gat_from_transform", "gcn_conv", "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum", "row_absmax", "linear_writes_amax", "linear_h3_preferred",
     "row_degree", "link_pred_head", "pack_weight_x6", "pack_weight_h3", "pack_weight_h3g", "gin_layer_h3", "gin_layer_h3_supported", "gin_layer_h3_codes", "gin_layer_h3_codes_supported", "linear_x6_supported", "gin_layer_x6", "gin_layer_x6_supported", "gin_stack", "molecule_tiles", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
     "require_device",
 ]
@@ -391,30 +391,45 @@ def linear(x, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn
     return y
 
 
-def gat_conv(csr, x, weight, att, bias, group="src", slope=0.2, act="identity", act_param=None,
-             bn_scale=None, bn_shift=None, out=None, accumulate=False):
-    """GATConv(heads=1) + the caller's act / eval-BN epilogue."""
-    if group not in GAT_GROUP:
-        raise ValueError("softmax_group must be 'src' or 'dst'")
+def gat_transform(x, weight, att, h=None):
+    """Row-wise front end of GATConv: h = x @ weight and both attention halves of every row.
+    -> (h [n, d], s [2, n]: s[0] = h . att[:d] (target half), s[1] = h . att[d:] (source half)).
+    ``h`` may be a column slice of a wider buffer.  Row-wise means shardable: a rank can transform its own
+    rows and exchange [n_r, d + 2] instead of the [n_r, K] inputs."""
     n, d = x.shape[0], weight.shape[1]
-    stats = torch.empty((4, n), dtype=torch.float32, device=x.device)
-    s_dst, s_src, mx, den = (stats[i].data_ptr() for i in range(4))
+    sc = torch.empty((2, n), dtype=torch.float32, device=x.device)
     attv = att.reshape(-1)
     s = _stream()
+    if weight.shape[0] != x.shape[1]:
+        raise ValueError("blgnn: x is [%d,%d] but w is [%d,%d]" % (n, x.shape[1], weight.shape[0], d))
     if d <= 128 and n < GAT_TRANSFORM_MAX_ROWS:
         # interaction level: x @ W and both attention halves in one split-K launch
         xp, ldx = _mat(x, "x")
         wp, ldw = _mat(weight, "w")
-        if weight.shape[0] != x.shape[1]:
-            raise ValueError("blgnn: x is [%d,%d] but w is [%d,%d]" % (n, x.shape[1], weight.shape[0], d))
-        h = torch.empty((n, d), dtype=torch.float32, device=x.device)
+        h = _out(h, n, d, x)
         hp, ldh = _mat(h, "h")
         call("blgnn_gat_transform", xp, ldx, wp, ldw, _vec(attv, "att", optional=False), n, d, x.shape[1],
-             hp, ldh, s_dst, s_src, s)
+             hp, ldh, sc[0].data_ptr(), sc[1].data_ptr(), s)
     else:
-        h = linear(x, weight)
+        h = linear(x, weight, out=h)
         hp, ldh = _mat(h, "h")
-        call("blgnn_gat_scores", hp, ldh, _vec(attv, "att", optional=False), n, d, s_dst, s_src, s)
+        call("blgnn_gat_scores", hp, ldh, _vec(attv, "att", optional=False), n, d, sc[0].data_ptr(), sc[1].data_ptr(), s)
+    return h, sc
+
+
+def gat_from_transform(csr, h, sc, bias, group="src", slope=0.2, act="identity", act_param=None,
+                       bn_scale=None, bn_shift=None, out=None, accumulate=False):
+    """The graph half of GATConv on an already transformed table: per-group softmax statistics and the
+    weighted neighbour sum + bias + the caller's act / eval-BN epilogue."""
+    if group not in GAT_GROUP:
+        raise ValueError("softmax_group must be 'src' or 'dst'")
+    n, d = h.shape
+    if tuple(sc.shape) != (2, n) or not sc.is_contiguous():
+        raise ValueError("blgnn: scores must be a contiguous [2, n] tensor")
+    stats = torch.empty((2, n), dtype=torch.float32, device=h.device)
+    s_dst, s_src, mx, den = sc[0].data_ptr(), sc[1].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr()
+    s = _stream()
+    hp, ldh = _mat(h, "h")
     call("blgnn_gat_softmax_stats", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, s_dst, s_src, n,
          GAT_GROUP[group], float(slope), mx, den, s)
     y = _out(out, n, d, h)
@@ -424,6 +439,15 @@ def gat_conv(csr, x, weight, att, bias, group="src", slope=0.2, act="identity", 
          _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"),
          int(bool(accumulate)), s)
     return y
+
+
+def gat_conv(csr, x, weight, att, bias, group="src", slope=0.2, act="identity", act_param=None,
+             bn_scale=None, bn_shift=None, out=None, accumulate=False):
+    """GATConv(heads=1) + the caller's act / eval-BN epilogue."""
+    if group not in GAT_GROUP:
+        raise ValueError("softmax_group must be 'src' or 'dst'")
+    h, sc = gat_transform(x, weight, att)
+    return gat_from_transform(csr, h, sc, bias, group, slope, act, act_param, bn_scale, bn_shift, out, accumulate)
 
 
 def gcn_conv(csr, x, weight, bias, edge_weight=None, act="identity", act_param=None,

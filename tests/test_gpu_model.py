@@ -280,6 +280,32 @@ def test_engine_graph_replay_and_two_stream_overlap_match_eager(device):
             eng.step(0)
 
 
+def test_engine_exchange_after_first_transform_is_bitwise_the_replicated_forward(device):
+    """multi-GPU decomposition, run at one rank: the first interaction layer's row-wise half (h = pooled @ W and
+    the two attention scores) applied to the rank's own pooled rows, the [N, d + 2] table exchanged instead of
+    [N, 5 d], the graph half on the gathered table -- the same bits as the replicated layer"""
+    from blgnn.engine import BiLevelEngine
+    ds = blgnn.make_synthetic(150, 1100, seed=23, device=device)
+    flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin",
+                             higher_level_gnn_type="gat", D_lower=128, D_higher=128, device=device)
+    model, data = build(flags, ds, seed=7)
+    lower = blgnn.BatchData(all_molecule_pairs(ds.molecules.gids), ds, is_train=False, ignore_pairs=True)
+    g = ds.interaction_combo_nxgraph
+    g.init_x = torch.zeros((ds.num_graphs(), 5 * 128), device=device)
+    ds.init = True
+    uppers = [blgnn.BatchData(_pairs(ds, 80, seed=k), ds, is_train=False) for k in range(2)]
+    plain = BiLevelEngine(model, lower, uppers, g, use_graph=False)
+    refs = [plain.eager_step(i).clone() for i in range(2)]
+    for use_graph in (False, True):
+        with BiLevelEngine(model, lower, uppers, g, use_graph=use_graph, exchange_transformed=True) as eng:
+            assert eng.exchange_transformed
+            eng.capture()
+            for i in range(4):
+                out = eng.step(i)
+                eng.synchronize()
+                assert torch.equal(out, refs[i % 2]), (use_graph, i)
+
+
 def test_engine_follows_weight_updates_after_capture(device):
     """captured graphs hold pointers to tensors derived from the weights (packed images, folded BN affines):
     an in-place weight / running-stat update after capture() must not leave step() replaying stale values"""
