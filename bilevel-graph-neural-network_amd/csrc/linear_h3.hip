@@ -25,6 +25,10 @@
 // ds_read_b128 serves together then cover all 16 chunk slots of the 256-byte bank row.
 // Workgroups that share an X row panel run on one XCD (ids remapped so an XCD owns a contiguous run
 // of tiles).
+// Tried and dropped: a 256 x 128 tile at K step 32 with ONE accumulator per tile (the second accumulator set
+// does not fit): 25 % fewer operand bytes per MFMA, but the feeder's 32 KB of X per step stays the same and
+// becomes the bound -- 3.71 ms vs 3.70 ms on 462 k x 1024 x 1024 (1.30 vs 1.44 ms at K = 256), with 1.7x the
+// rounding error (7.8e-7 vs 4.6e-7 of the largest entry).
 #include "linear_common.hpp"
 #include "h3_common.hpp"
 
