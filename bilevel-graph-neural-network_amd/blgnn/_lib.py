@@ -69,9 +69,18 @@ SIGNATURES = {
     "blgnn_scatter_rows": [_p, _i64, _p, _p, _i64, _i32, _i32, _p],
     "blgnn_stream_create_cu_mask": [_p, _i32, _p],
     "blgnn_stream_destroy": [_p],
+    "blgnn_col_reduce": [_p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, _f32, _p, _p, _p],
+    "blgnn_bn_apply": [_p, _i64, _p, _p, _p, _p, _i32, _i32, _p, _i64, _p],
+    "blgnn_bn_backward": [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i32, _i32, _p, _i64, _p],
+    "blgnn_act_backward": [_p, _i64, _p, _i64, _i32, _p, _i32, _i32, _p, _i64, _p],
+    "blgnn_transpose": [_p, _i64, _i32, _i32, _p, _i64, _p],
+    "blgnn_segment_broadcast": [_p, _i32, _p, _i64, _p, _i32, _i32, _p, _i64, _i32, _p],
+    "blgnn_l2_normalize_backward": [_p, _i64, _p, _i64, _i32, _i32, _f32, _p, _i64, _p],
+    "blgnn_pair_scatter_add": [_p, _i64, _i32, _p, _i32, _i32, _p, _i64, _p],
 }
 LIBRARY_SYMBOLS = ["blgnn_version", "blgnn_last_error", "blgnn_device_count", "blgnn_packed_weight_x6_elems",
-                   "blgnn_packed_weight_h3_elems", "blgnn_packed_weight_h3g_elems"]
+                   "blgnn_packed_weight_h3_elems", "blgnn_packed_weight_h3g_elems",
+                   "blgnn_col_reduce_scratch_elems"]
 
 _lib = None
 
@@ -104,6 +113,8 @@ def load():
     lib.blgnn_packed_weight_h3_elems.restype = ctypes.c_int64
     lib.blgnn_packed_weight_h3g_elems.argtypes = [_i32, _i32]
     lib.blgnn_packed_weight_h3g_elems.restype = ctypes.c_int64
+    lib.blgnn_col_reduce_scratch_elems.argtypes = [_i32, _i32]
+    lib.blgnn_col_reduce_scratch_elems.restype = ctypes.c_int64
     _lib = lib
     return lib
 

@@ -1,0 +1,208 @@
+"""Training step of the hot path: autograd nodes whose forward AND backward are libblgnn kernels.
+
+The reference trains with ``loss.backward(); optimizer.step()`` (src/train.py:177-182) on the same layer
+stack the forward path runs.  Here ``torch.autograd`` only records the graph and routes gradients (plumbing);
+every arithmetic step of both directions is a kernel behind the C ABI:
+
+  Linear (+act)      dX = g @ W            blgnn_linear on nn.Linear's own [out, in] weight
+                     dW = g^T @ X          blgnn_transpose + blgnn_linear (split-K over the rows)
+                     db = sum_rows g       blgnn_col_reduce;   g = dY * act'(Y): blgnn_act_backward
+  GIN aggregation    same CSR, same op     blgnn_spmm_sum (molecular graphs are symmetric)
+  BatchNorm1d train  statistics / dgamma / dbeta: blgnn_col_reduce; blgnn_bn_apply / blgnn_bn_backward
+  readout            blgnn_segment_broadcast per pooled activation
+  pair scorer        blgnn_l2_normalize_backward, blgnn_pair_scatter_add
+
+Scope: the lower-level GIN model ("lower_level_gnn": NodeEmbedding gin x L -> multi-scale
+readout -> mlp_concat pair scorer -> BCE), with relu / identity / sigmoid / tanh activations.  GAT / GCN / GMN
+layers raise NotImplementedError in training mode.
+"""
+
+import torch
+
+from . import ops
+
+__all__ = ["linear", "spmm_sum", "batch_norm_train", "segment_reduce_multi", "l2_normalize", "pair_gather",
+           "training_active"]
+
+
+def training_active(module):
+    """A module takes the autograd path when it is in train mode and gradients are being recorded."""
+    return module.training and torch.is_grad_enabled()
+
+
+def _check_act(act):
+    if act == "prelu":
+        raise NotImplementedError("blgnn: PReLU slopes are not trained on this path (relu / identity / sigmoid / tanh)")
+
+
+class _Linear(torch.autograd.Function):
+    """y = act(x @ weight^T + bias), weight in nn.Linear's [out, in] layout."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        _check_act(act)
+        w_kn = ops.transpose(weight.detach().contiguous())
+        y = ops.linear(x.detach(), w_kn, None if bias is None else bias.detach(), act=act, transform="f32")
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x.detach(), weight.detach(), y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        g = dy if ctx.act == "identity" else ops.act_backward(dy, y, ctx.act)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear(g, weight.contiguous(), transform="f32")              # [M, out] @ [out, in]
+        if ctx.needs_input_grad[1]:
+            dw = ops.linear(ops.transpose(g), x.contiguous(), transform="f32")    # [out, M] @ [M, in]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.col_reduce(g, "sum")
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, act="identity"):
+    return _Linear.apply(x, weight, bias, act)
+
+
+class _SpmmSum(torch.autograd.Function):
+    """agg_i = self_coef * x_i + sum_{j in N(i)} x_j on a SYMMETRIC CSR: the gradient is the same operator."""
+
+    @staticmethod
+    def forward(ctx, x, csr, self_coef):
+        ctx.csr, ctx.self_coef = csr, self_coef
+        return ops.spmm_sum(csr, x.detach(), self_coef=self_coef, skip_self=True)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.spmm_sum(ctx.csr, dy.contiguous(), self_coef=ctx.self_coef, skip_self=True), None, None
+
+
+def spmm_sum(x, csr, self_coef):
+    return _SpmmSum.apply(x, csr, self_coef)
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, stats_out):
+        x = x.detach()
+        M = x.shape[0]
+        mean = ops.col_reduce(x, "sum", scale=1.0 / M)
+        var = ops.col_reduce(x, "sqdev", mean=mean, scale=1.0 / M)                # biased, two-pass
+        rstd = torch.rsqrt(var + eps)                                             # [N] vector glue
+        y = ops.bn_apply(x, mean, rstd, None if gamma is None else gamma.detach(),
+                         None if beta is None else beta.detach())
+        stats_out.extend((mean, var))
+        ctx.save_for_backward(x, mean, rstd, gamma.detach() if gamma is not None else None)
+        ctx.has_affine = gamma is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        M = x.shape[0]
+        dbeta = ops.col_reduce(dy, "sum")
+        dgamma = ops.col_reduce(dy, "dot_norm", b=x, mean=mean, rstd=rstd)        # sum dy * xhat
+        dx = ops.bn_backward(dy, x, mean, rstd, gamma, dgamma, dbeta) if ctx.needs_input_grad[0] else None
+        return dx, (dgamma if ctx.has_affine else None), (dbeta if ctx.has_affine else None), None, None
+
+
+def batch_norm_train(x, bn):
+    """torch.nn.BatchNorm1d in train mode (model/layers.py:39-40,56-57), including the running-statistics
+    update (momentum form, unbiased variance) torch performs as a side effect."""
+    stats = []
+    y = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps, stats)
+    if bn.track_running_stats and bn.running_mean is not None:
+        mean, var = stats
+        M = x.shape[0]
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1.0 - mom).add_(var * (M / max(M - 1, 1)), alpha=mom)
+    return y
+
+
+class _SegmentReduceMulti(torch.autograd.Function):
+    """torch.cat([scatter_mean(x, batch) for x in xs], dim=1) and its gradient."""
+
+    @staticmethod
+    def forward(ctx, seg, kind, row_map, *xs):
+        ctx.seg, ctx.kind, ctx.row_map = seg, kind, row_map
+        ctx.shapes = [tuple(x.shape) for x in xs]
+        xs = [x.detach() for x in xs]
+        if len(xs) <= 8:
+            return ops.segment_reduce_multi(seg, xs, kind, row_map=row_map)
+        G = seg.numel() - 1
+        out = torch.empty((G, sum(s[1] for s in ctx.shapes)), dtype=torch.float32, device=xs[0].device)
+        c = 0
+        for x in xs:
+            ops.segment_reduce(seg, x, kind, out=out[:, c:c + x.shape[1]], row_map=row_map)
+            c += x.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, dp):
+        grads, c = [], 0
+        if dp.stride(1) != 1:
+            dp = dp.contiguous()
+        for i, (n, d) in enumerate(ctx.shapes):
+            if ctx.needs_input_grad[3 + i]:
+                grads.append(ops.segment_broadcast(ctx.seg, dp[:, c:c + d], n, ctx.kind, row_map=ctx.row_map))
+            else:
+                grads.append(None)
+            c += d
+        return (None, None, None) + tuple(grads)
+
+
+def segment_reduce_multi(seg, xs, kind="mean", row_map=None):
+    return _SegmentReduceMulti.apply(seg, kind, row_map, *xs)
+
+
+class _L2Normalize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, eps):
+        z = z.detach()
+        ctx.eps = eps
+        ctx.save_for_backward(z)
+        return ops.l2_normalize_rows(z, eps)
+
+    @staticmethod
+    def backward(ctx, dzn):
+        (z,) = ctx.saved_tensors
+        return ops.l2_normalize_backward(z, dzn.contiguous(), ctx.eps), None
+
+
+def l2_normalize(z, eps=1e-12):
+    return _L2Normalize.apply(z, eps)
+
+
+class _PairGather(torch.autograd.Function):
+    """cat[b] = [zn[ids1[b]], zn[ids2[b]]]  (model/layers_link_pred.py:56-61); gradient = scatter-add."""
+
+    @staticmethod
+    def forward(ctx, zn, ids1, ids2):
+        ctx.ids = (ids1, ids2)
+        ctx.shape = tuple(zn.shape)
+        zn = zn.detach()
+        d = zn.shape[1]
+        cat = torch.empty((ids1.numel(), 2 * d), dtype=torch.float32, device=zn.device)
+        cat[:, :d] = zn.index_select(0, ids1)                  # row copies: data movement only
+        cat[:, d:] = zn.index_select(0, ids2)
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        dcat = dcat.contiguous()
+        dz = torch.zeros(ctx.shape, dtype=torch.float32, device=dcat.device)
+        d = ctx.shape[1]
+        ops.pair_scatter_add(dcat, 0, ctx.ids[0], dz)
+        ops.pair_scatter_add(dcat, d, ctx.ids[1], dz)
+        return dz, None, None
+
+
+def pair_gather(zn, ids1, ids2):
+    return _PairGather.apply(zn, ids1, ids2)

@@ -14,6 +14,7 @@ import math
 import torch
 import torch.nn as nn
 
+from . import autograd as ag
 from . import ops
 from .config import FLAGS
 from .layers_util import create_act, act_name, DerivedCache, bn_affine, prelu_slopes
@@ -97,6 +98,8 @@ class NodeEmbedding(nn.Module):
         """``out`` (optional) lets the caller place the result in a column slice of
         a wider buffer (multi-scale readout / GMN f_node input)."""
         ops.require_device(ins, "ins")
+        if ag.training_active(self):
+            return self._forward_train(ins, batch_data, model, out)
         csr = self._graph(batch_data).csr()
         act = act_name(self.act)
         slopes = prelu_slopes(self._cache, "prelu", self.act, self.out_dim)
@@ -157,6 +160,29 @@ class NodeEmbedding(nn.Module):
                 x = ops.l2_normalize_rows(x)
         return x
 
+
+    def _forward_train(self, ins, batch_data, model, out=None):
+        """Train mode (src/train.py:177-182 runs backward through this layer): the same arithmetic as
+        ``forward`` unfused -- aggregation, Linear+act, Linear+act, train-mode BatchNorm -- as autograd nodes whose
+        both directions are libblgnn kernels (blgnn/autograd.py)."""
+        if self.type != 'gin' or self.higher_level:
+            raise NotImplementedError(
+                "blgnn: training is implemented for the lower-level GIN layers; '{}' layers run forward-only "
+                "(call model.eval() / torch.no_grad())".format(self.type))
+        if out is not None:
+            raise NotImplementedError("blgnn: train mode does not write into a caller-provided slice")
+        csr = self._graph(batch_data).csr()
+        act = act_name(self.act)
+        lin1, lin2 = self.conv.nn[0], self.conv.nn[2]
+        agg = ag.spmm_sum(ins, csr, 1.0 + float(self.conv.eps[0]))
+        h = ag.linear(agg, lin1.weight, lin1.bias, act)
+        x = ag.linear(h, lin2.weight, lin2.bias, act)           # conv, then the layer's act (layers.py:55)
+        if self.bn:
+            x = ag.batch_norm_train(x, self.bn)
+        model.store_layer_output(self, x)
+        if self.normalize:
+            x = ag.l2_normalize(x)
+        return x
 
     # ---- GAT split at its row-wise / graph-wise seam (multi-GPU: blgnn/engine.py) -------------------------
     def gat_transform_rows(self, x, h=None):

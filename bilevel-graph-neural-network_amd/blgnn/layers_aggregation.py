@@ -11,6 +11,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import autograd as ag
 from . import ops
 from .config import FLAGS
 from .layers_util import MLP
@@ -53,6 +54,15 @@ class NodeAggregationPairs(nn.Module):
     def forward(self, ins, batch_data, model, pair_batch=False, out=None):
         ops.require_device(ins, "ins")
         seg = _segments(batch_data, pair_batch)
+        if ag.training_active(self) and ins.requires_grad:
+            if not isinstance(self.agg_func, _SegmentPool) or out is not None:
+                raise NotImplementedError("blgnn: training covers the avg_pool / sum readouts of the lower-level model")
+            if self.concat_multi_scale:
+                xs = model.acts[1:] if 'gmn' not in FLAGS.model else \
+                    [x for i, x in enumerate(model.acts[1:]) if i % 2 == 1]
+            else:
+                xs = [ins]
+            return ag.segment_reduce_multi(seg, xs, self.agg_func.kind)
         with torch.no_grad():
             if self.concat_multi_scale:
                 if 'gmn' not in FLAGS.model:

@@ -9,6 +9,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import autograd as ag
 from . import ops
 from .config import FLAGS
 from .layers_util import MLP, act_name
@@ -69,6 +70,13 @@ class LinkPred(nn.Module):
             batch_data._pair_row_ids = ids
         ids1, ids2 = ids
         mlp = getattr(self, "mlp_concat", None)
+        if ag.training_active(self) and ins.requires_grad:
+            if self.type != "mlp_concat":
+                raise NotImplementedError("blgnn: training covers the mlp_concat pair scorer")
+            cat = ag.pair_gather(ag.l2_normalize(ins), ids1, ids2)
+            pair_preds = self.mlp_concat(cat, final_act="identity" if self.multi_label_pred else "sigmoid")
+            batch_data.pair_preds = pair_preds
+            return pair_preds
         with torch.no_grad():
             # fused head for the interaction-level widths; wider graph embeddings (multi-scale readout of a
             # lower-level-only model at d=256: 768 per graph) go through gather + the matrix-core GEMMs: the

@@ -144,6 +144,14 @@ class MLP(nn.Module):
         epilogue (f16x3 path), so only the first layer may need a pass over its input."""
         act = act_name(self.activation)
         last = len(self.layers) - 1
+        if self.training and torch.is_grad_enabled() and x.requires_grad:
+            # train mode: Linear(+act) autograd nodes on libblgnn kernels (blgnn/autograd.py)
+            from . import autograd as ag
+            if self.bn or first_rowvec is not None or out is not None:
+                raise NotImplementedError("blgnn: training covers MLPs without BatchNorm (the pair scorer's)")
+            for i, lin in enumerate(self.layers):
+                x = ag.linear(x, lin.weight, lin.bias, final_act if i == last else act)
+            return x
         amax = row_amax
         for i, lin in enumerate(self.layers):
             kw = {}

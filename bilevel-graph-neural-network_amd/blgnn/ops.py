@@ -578,3 +578,92 @@ def scatter_rows(src, row_map, dst):
     call("blgnn_scatter_rows", sp, lds, _vec(row_map, "row_map", torch.int32, False), dp, ldd,
          src.shape[0], src.shape[1], _stream())
     return dst
+
+
+# ---- backward pass / train mode (include/blgnn.h "backward pass" block) -------------------------------------
+
+_COL_MODES = {"sum": 0, "dot": 1, "sqdev": 2, "dot_norm": 3}
+
+
+def col_reduce(a, mode="sum", b=None, mean=None, rstd=None, scale=1.0, out=None):
+    """Deterministic column reduction over all rows: sum a | sum a*b | sum (a - mean)^2 |
+    sum a * (b - mean) * rstd, times ``scale``."""
+    ap, lda = _mat(a, "a")
+    M, N = a.shape
+    bp, ldb = (None, 0) if b is None else _mat(b, "b")
+    if b is not None and tuple(b.shape) != (M, N):
+        raise ValueError("blgnn: col_reduce operands differ in shape")
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=a.device)
+    scratch = torch.empty(max(int(_lib.load().blgnn_col_reduce_scratch_elems(M, N)), 1), dtype=torch.float32, device=a.device)
+    call("blgnn_col_reduce", ap, lda, bp, ldb, _vec(mean, "mean"), _vec(rstd, "rstd"), M, N, _COL_MODES[mode], float(scale),
+         scratch.data_ptr(), _vec(out, "out", optional=False), _stream())
+    return out
+
+
+def bn_apply(x, mean, rstd, gamma=None, beta=None, out=None):
+    xp, ldx = _mat(x, "x")
+    y = _out(out, x.shape[0], x.shape[1], x)
+    yp, ldy = _mat(y, "out")
+    call("blgnn_bn_apply", xp, ldx, _vec(mean, "mean", optional=False), _vec(rstd, "rstd", optional=False),
+         _vec(gamma, "gamma"), _vec(beta, "beta"), x.shape[0], x.shape[1], yp, ldy, _stream())
+    return y
+
+
+def bn_backward(dy, x, mean, rstd, gamma, dgamma, dbeta, out=None):
+    dyp, lddy = _mat(dy, "dy")
+    xp, ldx = _mat(x, "x")
+    dx = _out(out, x.shape[0], x.shape[1], x)
+    dxp, lddx = _mat(dx, "out")
+    call("blgnn_bn_backward", dyp, lddy, xp, ldx, _vec(mean, "mean", optional=False), _vec(rstd, "rstd", optional=False),
+         _vec(gamma, "gamma"), _vec(dgamma, "dgamma", optional=False), _vec(dbeta, "dbeta", optional=False),
+         x.shape[0], x.shape[1], dxp, lddx, _stream())
+    return dx
+
+
+def act_backward(dy, y, act, slope=None, out=None):
+    dyp, lddy = _mat(dy, "dy")
+    yp, ldy = _mat(y, "y")
+    dx = _out(out, y.shape[0], y.shape[1], y)
+    dxp, lddx = _mat(dx, "out")
+    call("blgnn_act_backward", dyp, lddy, yp, ldy, _act(act), _vec(slope, "slope"), y.shape[0], y.shape[1], dxp, lddx,
+         _stream())
+    return dx
+
+
+def transpose(x, out=None):
+    xp, ldx = _mat(x, "x")
+    M, N = x.shape
+    y = _out(out, N, M, x)
+    yp, ldy = _mat(y, "out")
+    call("blgnn_transpose", xp, ldx, M, N, yp, ldy, _stream())
+    return y
+
+
+def segment_broadcast(seg, dp, n_rows, kind="mean", row_map=None, out=None, accumulate=False):
+    """Gradient of ``segment_reduce``: rows of segment g receive dp[g] (/ count for mean)."""
+    dpp, lddp = _mat(dp, "dp")
+    G, d = seg.numel() - 1, dp.shape[1]
+    dx = _out(out, n_rows, d, dp)
+    dxp, lddx = _mat(dx, "out")
+    call("blgnn_segment_broadcast", _vec(seg, "seg", torch.int32, False), G, dpp, lddp,
+         _vec(row_map, "row_map", torch.int32), d, REDUCE_MEAN if kind == "mean" else REDUCE_SUM, dxp, lddx,
+         int(bool(accumulate)), _stream())
+    return dx
+
+
+def l2_normalize_backward(z, dzn, eps=1e-12, out=None):
+    zp, ldz = _mat(z, "z")
+    gp, ldg = _mat(dzn, "dzn")
+    dz = _out(out, z.shape[0], z.shape[1], z)
+    dzp, lddz = _mat(dz, "out")
+    call("blgnn_l2_normalize_backward", zp, ldz, gp, ldg, z.shape[0], z.shape[1], float(eps), dzp, lddz, _stream())
+    return dz
+
+
+def pair_scatter_add(dcat, col0, ids, dz):
+    cp, ldc = _mat(dcat, "dcat")
+    dzp, lddz = _mat(dz, "dz")
+    call("blgnn_pair_scatter_add", cp, ldc, int(col0), _vec(ids, "ids", torch.int64, False), ids.numel(), dz.shape[1],
+         dzp, lddz, _stream())
+    return dz

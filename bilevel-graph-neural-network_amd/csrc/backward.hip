@@ -1,0 +1,271 @@
+// Backward-pass and train-mode kernels (what src/train.py:177-182 --
+// loss.backward(); optimizer.step() -- needs from this path for the lower-level GIN model).
+//
+// The big products of the backward pass reuse the forward kernels: dX = dY @ W is blgnn_linear on
+// nn.Linear's own [out, in] weight, dW = dY^T @ X is blgnn_linear on a transposed copy of dY (split-K
+// over the rows, two-level accumulation), the GIN aggregation's gradient is blgnn_spmm_sum on the same
+// CSR (the molecular graphs are symmetric).  What is new here are the reductions and the pointwise
+// pieces around them:
+//   * column reductions over all rows (bias gradients, train-mode BatchNorm statistics and gradients):
+//     per 512-row chunk partial sums + a fixed-order final pass -- deterministic, no atomics;
+//   * BatchNorm1d train forward / backward (model/layers.py:39-40,56-57), activation backward;
+//   * tiled transpose;
+//   * segment-mean / segment-sum backward (the readout's gradient: model/layers_aggregation.py:16-19);
+//   * L2-normalise backward and the pair gather's scatter-add (model/layers_link_pred.py:44,56-61).
+// All are HBM-bound: rows are read with 16-byte accesses where alignment allows.
+#include "common.hpp"
+
+namespace blgnn {
+
+constexpr int CR_ROWS = 512;            // rows per partial-reduction chunk
+enum { COL_SUM = 0, COL_DOT = 1, COL_SQDEV = 2, COL_DOT_NORM = 3 };
+
+// partial[chunk][c] = sum over the chunk's rows of  a  |  a * b  |  (a - mean[c])^2  |  a * (b - mean[c]) * rstd[c]
+template <int MODE>
+__global__ void __launch_bounds__(256) k_col_partial(const float *__restrict__ a, int64_t lda,
+                                                     const float *__restrict__ b, int64_t ldb,
+                                                     const float *__restrict__ mean,
+                                                     const float *__restrict__ rstd, int M, int N,
+                                                     float *__restrict__ partial) {
+    // 64 columns x 4 row lanes per workgroup pass; grid = (column strips of 64, row chunks)
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;                                  // 0..3
+    const int r0 = blockIdx.y * CR_ROWS;
+    const int r1 = min(r0 + CR_ROWS, M);
+    float s = 0.f;
+    if (c < N) {
+        const float mu = (MODE == COL_SQDEV || MODE == COL_DOT_NORM) ? mean[c] : 0.f;
+        const float rs = MODE == COL_DOT_NORM ? rstd[c] : 1.f;
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const float v = a[(int64_t)r * lda + c];
+            if (MODE == COL_SUM) s += v;
+            else if (MODE == COL_DOT) s = fmaf(v, b[(int64_t)r * ldb + c], s);
+            else if (MODE == COL_DOT_NORM) s = fmaf(v, (b[(int64_t)r * ldb + c] - mu) * rs, s);
+            else { const float dlt = v - mu; s = fmaf(dlt, dlt, s); }
+        }
+    }
+    __shared__ float red[4][64];
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < N)
+        partial[(int64_t)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) +
+                                               (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void k_col_final(const float *__restrict__ partial, int chunks, int N, float scale, float *__restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += partial[(int64_t)k * N + c];     // fixed order
+    out[c] = s * scale;
+}
+
+// y = (x - mean) * rstd * gamma + beta
+__global__ void k_bn_apply(const float *__restrict__ x, int64_t ldx, const float *__restrict__ mean,
+                           const float *__restrict__ rstd, const float *__restrict__ gamma,
+                           const float *__restrict__ beta, int M, int N, float *__restrict__ y, int64_t ldy) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)M * N) return;
+    const int r = (int)(idx / N), c = (int)(idx % N);
+    y[(int64_t)r * ldy + c] = fmaf((x[(int64_t)r * ldx + c] - mean[c]) * rstd[c], gamma ? gamma[c] : 1.f, beta ? beta[c] : 0.f);
+}
+
+// dx = gamma * rstd * (dy - dbeta / M - xhat * dgamma / M),  xhat = (x - mean) * rstd
+__global__ void k_bn_backward(const float *__restrict__ dy, int64_t lddy, const float *__restrict__ x, int64_t ldx,
+                              const float *__restrict__ mean, const float *__restrict__ rstd,
+                              const float *__restrict__ gamma, const float *__restrict__ dgamma,
+                              const float *__restrict__ dbeta, int M, int N, float *__restrict__ dx, int64_t lddx) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)M * N) return;
+    const int r = (int)(idx / N), c = (int)(idx % N);
+    const float xh = (x[(int64_t)r * ldx + c] - mean[c]) * rstd[c];
+    const float inv_m = 1.f / (float)M;
+    dx[(int64_t)r * lddx + c] = (gamma ? gamma[c] : 1.f) * rstd[c] *
+                                (dy[(int64_t)r * lddy + c] - dbeta[c] * inv_m - xh * dgamma[c] * inv_m);
+}
+
+// dx = dy * act'(.) from the activation's OUTPUT y: relu y > 0, prelu (y > 0 ? 1 : slope; slope > 0 assumed for
+// the sign test on y), sigmoid y (1 - y), tanh 1 - y^2, identity 1.  dslope (PReLU, optional) is not produced here.
+__global__ void k_act_backward(const float *__restrict__ dy, int64_t lddy, const float *__restrict__ y, int64_t ldy,
+                               int act, const float *__restrict__ slope, int M, int N, float *__restrict__ dx,
+                               int64_t lddx) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)M * N) return;
+    const int r = (int)(idx / N), c = (int)(idx % N);
+    const float g = dy[(int64_t)r * lddy + c], v = y[(int64_t)r * ldy + c];
+    float d = 1.f;
+    if (act == BLGNN_ACT_RELU) d = v > 0.f ? 1.f : 0.f;
+    else if (act == BLGNN_ACT_PRELU) d = v > 0.f ? 1.f : (slope ? slope[c] : 0.f);
+    else if (act == BLGNN_ACT_SIGMOID) d = v * (1.f - v);
+    else if (act == BLGNN_ACT_TANH) d = 1.f - v * v;
+    dx[(int64_t)r * lddx + c] = g * d;
+}
+
+// y[N, M] = x[M, N]^T through a padded 32 x 32 LDS tile
+__global__ void __launch_bounds__(256) k_transpose(const float *__restrict__ x, int64_t ldx, int M, int N,
+                                                   float *__restrict__ y, int64_t ldy) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int m = m0 + ty + 8 * k, n = n0 + tx;
+        tile[ty + 8 * k][tx] = (m < M && n < N) ? x[(int64_t)m * ldx + n] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int n = n0 + ty + 8 * k, m = m0 + tx;
+        if (n < N && m < M) y[(int64_t)n * ldy + m] = tile[tx][ty + 8 * k];
+    }
+}
+
+// readout backward: dx[i, :] (+)= dp[row_of(g(i)), :] * (mean ? 1 / max(count_g, 1) : 1)
+__global__ void k_segment_broadcast(const int32_t *__restrict__ seg, int G, const float *__restrict__ dp, int64_t lddp,
+                                    const int32_t *__restrict__ row_map, int d, int mean, float *__restrict__ dx,
+                                    int64_t lddx, int accumulate) {
+    const int g = blockIdx.x;
+    if (g >= G) return;
+    const int r0 = seg[g], r1 = seg[g + 1];
+    const float w = mean ? 1.f / (float)max(r1 - r0, 1) : 1.f;
+    const float *src = dp + (int64_t)(row_map ? row_map[g] : g) * lddp;
+    for (int idx = threadIdx.x; idx < (r1 - r0) * d; idx += blockDim.x) {
+        const int r = r0 + idx / d, c = idx % d;
+        float *dst = dx + (int64_t)r * lddx + c;
+        const float v = src[c] * w;
+        *dst = accumulate ? *dst + v : v;
+    }
+}
+
+// zn = z / max(|z|, eps) row-wise  ->  dz = (dzn - zn (zn . dzn)) / max(|z|, eps)   (rows with |z| < eps: dzn / eps)
+__global__ void __launch_bounds__(256) k_l2_normalize_backward(const float *__restrict__ z, int64_t ldz,
+                                                               const float *__restrict__ dzn, int64_t lddzn, int M, int d,
+                                                               float eps, float *__restrict__ dz, int64_t lddz) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float *zr = z + (int64_t)row * ldz, *gr = dzn + (int64_t)row * lddzn;
+    float nn = 0.f, dot = 0.f;
+    for (int c = lane; c < d; c += 64) { nn = fmaf(zr[c], zr[c], nn); dot = fmaf(zr[c], gr[c], dot); }
+    nn = group_sum(nn, WAVE); dot = group_sum(dot, WAVE);
+    const float norm = sqrtf(nn);
+    float *out = dz + (int64_t)row * lddz;
+    if (norm < eps) {
+        for (int c = lane; c < d; c += 64) out[c] = gr[c] / eps;
+    } else {
+        const float inv = 1.f / norm, k = dot * inv * inv * inv;     // zn (zn . g) / |z| = z (z . g) / |z|^3
+        for (int c = lane; c < d; c += 64) out[c] = fmaf(-k, zr[c], gr[c] * inv);
+    }
+}
+
+// dz[ids[b], :] += dcat[b, col0 : col0 + d]  (several pairs may name the same graph: float atomics at the memory side)
+__global__ void k_pair_scatter_add(const float *__restrict__ dcat, int64_t ldc, int col0, const int64_t *__restrict__ ids,
+                                   int B, int d, float *__restrict__ dz, int64_t lddz) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * d) return;
+    const int b = (int)(idx / d), c = (int)(idx % d);
+    atomicAdd(dz + ids[b] * lddz + c, dcat[(int64_t)b * ldc + col0 + c]);
+}
+
+static unsigned grid_for(int64_t items, int threads) { return (unsigned)((items + threads - 1) / threads); }
+
+}  // namespace blgnn
+
+using namespace blgnn;
+
+extern "C" int64_t blgnn_col_reduce_scratch_elems(int32_t M, int32_t N) {
+    return (int64_t)((M + CR_ROWS - 1) / CR_ROWS) * N;
+}
+
+extern "C" int blgnn_col_reduce(const float *a, int64_t lda, const float *b, int64_t ldb, const float *mean,
+                                const float *rstd, int32_t M, int32_t N, int32_t mode, float scale, float *scratch,
+                                float *out, void *stream) {
+    BLGNN_CHECK_ARG(M >= 0 && N > 0 && mode >= COL_SUM && mode <= COL_DOT_NORM, "col_reduce: bad sizes / mode");
+    BLGNN_CHECK_ARG(a && out && scratch && lda >= N, "col_reduce: null pointer / leading dimension");
+    BLGNN_CHECK_ARG((mode != COL_DOT && mode != COL_DOT_NORM) || (b && ldb >= N), "col_reduce: dot modes need b");
+    BLGNN_CHECK_ARG((mode != COL_SQDEV && mode != COL_DOT_NORM) || mean, "col_reduce: this mode needs the column means");
+    BLGNN_CHECK_ARG(mode != COL_DOT_NORM || rstd, "col_reduce: dot_norm mode needs rstd");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = (M + CR_ROWS - 1) / CR_ROWS;
+    if (chunks > 0) {
+        dim3 grid((N + 63) / 64, chunks);
+        if (mode == COL_SUM) hipLaunchKernelGGL(k_col_partial<COL_SUM>, grid, dim3(256), 0, s, a, lda, b, ldb, mean, rstd, M, N, scratch);
+        else if (mode == COL_DOT) hipLaunchKernelGGL(k_col_partial<COL_DOT>, grid, dim3(256), 0, s, a, lda, b, ldb, mean, rstd, M, N, scratch);
+        else if (mode == COL_SQDEV) hipLaunchKernelGGL(k_col_partial<COL_SQDEV>, grid, dim3(256), 0, s, a, lda, b, ldb, mean, rstd, M, N, scratch);
+        else hipLaunchKernelGGL(k_col_partial<COL_DOT_NORM>, grid, dim3(256), 0, s, a, lda, b, ldb, mean, rstd, M, N, scratch);
+    }
+    hipLaunchKernelGGL(k_col_final, dim3((N + 255) / 256), dim3(256), 0, s, scratch, chunks, N, scale, out);
+    return launch_status("col_reduce");
+}
+
+extern "C" int blgnn_bn_apply(const float *x, int64_t ldx, const float *mean, const float *rstd, const float *gamma,
+                              const float *beta, int32_t M, int32_t N, float *y, int64_t ldy, void *stream) {
+    BLGNN_CHECK_ARG(M >= 0 && N > 0 && ldx >= N && ldy >= N, "bn_apply: bad sizes");
+    if (M == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(x && mean && rstd && y, "bn_apply: null pointer");
+    hipLaunchKernelGGL(k_bn_apply, dim3(grid_for((int64_t)M * N, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, mean, rstd,
+                       gamma, beta, M, N, y, ldy);
+    return launch_status("bn_apply");
+}
+
+extern "C" int blgnn_bn_backward(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *mean,
+                                 const float *rstd, const float *gamma, const float *dgamma, const float *dbeta,
+                                 int32_t M, int32_t N, float *dx, int64_t lddx, void *stream) {
+    BLGNN_CHECK_ARG(M >= 0 && N > 0 && lddy >= N && ldx >= N && lddx >= N, "bn_backward: bad sizes");
+    if (M == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(dy && x && mean && rstd && dgamma && dbeta && dx, "bn_backward: null pointer");
+    hipLaunchKernelGGL(k_bn_backward, dim3(grid_for((int64_t)M * N, 256)), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx,
+                       mean, rstd, gamma, dgamma, dbeta, M, N, dx, lddx);
+    return launch_status("bn_backward");
+}
+
+extern "C" int blgnn_act_backward(const float *dy, int64_t lddy, const float *y, int64_t ldy, int32_t act,
+                                  const float *slope, int32_t M, int32_t N, float *dx, int64_t lddx, void *stream) {
+    BLGNN_CHECK_ARG(M >= 0 && N > 0 && lddy >= N && ldy >= N && lddx >= N, "act_backward: bad sizes");
+    BLGNN_CHECK_ARG(act >= 0 && act <= BLGNN_ACT_TANH, "act_backward: bad activation id");
+    if (M == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(dy && y && dx, "act_backward: null pointer");
+    hipLaunchKernelGGL(k_act_backward, dim3(grid_for((int64_t)M * N, 256)), dim3(256), 0, (hipStream_t)stream, dy, lddy, y, ldy,
+                       act, slope, M, N, dx, lddx);
+    return launch_status("act_backward");
+}
+
+extern "C" int blgnn_transpose(const float *x, int64_t ldx, int32_t M, int32_t N, float *y, int64_t ldy, void *stream) {
+    BLGNN_CHECK_ARG(M >= 0 && N >= 0 && ldx >= N && ldy >= M, "transpose: bad sizes");
+    if (M == 0 || N == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(x && y && x != y, "transpose: null / aliased pointer");
+    hipLaunchKernelGGL(k_transpose, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, ldx, M, N, y, ldy);
+    return launch_status("transpose");
+}
+
+extern "C" int blgnn_segment_broadcast(const int32_t *seg, int32_t G, const float *dp, int64_t lddp,
+                                       const int32_t *row_map, int32_t d, int32_t kind, float *dx, int64_t lddx,
+                                       int32_t accumulate, void *stream) {
+    BLGNN_CHECK_ARG(G >= 0 && d > 0 && lddp >= d && lddx >= d, "segment_broadcast: bad sizes");
+    BLGNN_CHECK_ARG(kind == BLGNN_REDUCE_SUM || kind == BLGNN_REDUCE_MEAN, "segment_broadcast: bad reduce kind");
+    if (G == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(seg && dp && dx, "segment_broadcast: null pointer");
+    hipLaunchKernelGGL(k_segment_broadcast, dim3(G), dim3(256), 0, (hipStream_t)stream, seg, G, dp, lddp, row_map, d,
+                       kind == BLGNN_REDUCE_MEAN, dx, lddx, accumulate);
+    return launch_status("segment_broadcast");
+}
+
+extern "C" int blgnn_l2_normalize_backward(const float *z, int64_t ldz, const float *dzn, int64_t lddzn, int32_t M,
+                                           int32_t d, float eps, float *dz, int64_t lddz, void *stream) {
+    BLGNN_CHECK_ARG(M >= 0 && d > 0 && ldz >= d && lddzn >= d && lddz >= d && eps > 0.f, "l2_normalize_backward: bad sizes");
+    if (M == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(z && dzn && dz, "l2_normalize_backward: null pointer");
+    hipLaunchKernelGGL(k_l2_normalize_backward, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, ldz, dzn, lddzn, M, d,
+                       eps, dz, lddz);
+    return launch_status("l2_normalize_backward");
+}
+
+extern "C" int blgnn_pair_scatter_add(const float *dcat, int64_t ldc, int32_t col0, const int64_t *ids, int32_t B,
+                                      int32_t d, float *dz, int64_t lddz, void *stream) {
+    BLGNN_CHECK_ARG(B >= 0 && d > 0 && col0 >= 0 && ldc >= col0 + d && lddz >= d, "pair_scatter_add: bad sizes");
+    if (B == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(dcat && ids && dz, "pair_scatter_add: null pointer");
+    hipLaunchKernelGGL(k_pair_scatter_add, dim3(grid_for((int64_t)B * d, 256)), dim3(256), 0, (hipStream_t)stream, dcat, ldc,
+                       col0, ids, B, d, dz, lddz);
+    return launch_status("pair_scatter_add");
+}

@@ -373,6 +373,66 @@ int blgnn_l2_normalize_rows(const float *x, int64_t ldx, float *y, int64_t ldy,
 int blgnn_scatter_rows(const float *src, int64_t lds, const int32_t *row_map,
                        float *dst, int64_t ldd, int32_t G, int32_t d, void *stream);
 
+/* ---- backward pass / train mode (src/train.py:177-182) -------------------- */
+/* The large products of the backward pass are the forward entry points on other operands:
+ *   dX = dY @ W        -> blgnn_linear(dY, w_kn = nn.Linear.weight ([out, in] IS [K'=out, N'=in]))
+ *   dW = dY^T @ X      -> blgnn_transpose(dY) then blgnn_linear(dY^T [out, M], w_kn = X [M, in])
+ *   GIN aggregation    -> blgnn_spmm_sum on the same (symmetric) CSR
+ * The entry points below are the reductions and pointwise pieces around them. */
+
+#define BLGNN_COL_SUM   0   /* out[c] = scale * sum_m a[m, c]                       */
+#define BLGNN_COL_DOT   1   /* out[c] = scale * sum_m a[m, c] * b[m, c]             */
+#define BLGNN_COL_SQDEV 2   /* out[c] = scale * sum_m (a[m, c] - mean[c])^2         */
+#define BLGNN_COL_DOT_NORM 3 /* out[c] = scale * sum_m a[m, c] * (b[m, c] - mean[c]) * rstd[c] */
+
+/* Column reduction over all M rows: bias gradients (sum of dY), train-mode BatchNorm1d statistics
+ * (model/layers.py:39-40: mean = COL_SUM / M, biased var = COL_SQDEV / M, two-pass like torch) and its
+ * gradients (dbeta = COL_SUM(dy), dgamma = COL_DOT_NORM(dy, x)).  Deterministic: per-512-row partial sums
+ * in scratch (blgnn_col_reduce_scratch_elems(M, N) floats) then a fixed-order final pass. */
+int64_t blgnn_col_reduce_scratch_elems(int32_t M, int32_t N);
+int blgnn_col_reduce(const float *a, int64_t lda, const float *b, int64_t ldb, const float *mean,
+                     const float *rstd, int32_t M, int32_t N, int32_t mode, float scale,
+                     float *scratch, float *out, void *stream);
+
+/* Train-mode BatchNorm1d forward: y = (x - mean) * rstd * gamma + beta (gamma / beta nullable). */
+int blgnn_bn_apply(const float *x, int64_t ldx, const float *mean, const float *rstd,
+                   const float *gamma, const float *beta, int32_t M, int32_t N, float *y,
+                   int64_t ldy, void *stream);
+
+/* Train-mode BatchNorm1d backward given dgamma = sum dy * xhat and dbeta = sum dy:
+ *   dx = gamma * rstd * (dy - dbeta / M - xhat * dgamma / M),  xhat = (x - mean) * rstd. */
+int blgnn_bn_backward(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *mean,
+                      const float *rstd, const float *gamma, const float *dgamma,
+                      const float *dbeta, int32_t M, int32_t N, float *dx, int64_t lddx,
+                      void *stream);
+
+/* dx = dy * act'(.) evaluated from the activation's OUTPUT y (relu / prelu with positive slopes /
+ * sigmoid / tanh / identity); dx may alias dy. */
+int blgnn_act_backward(const float *dy, int64_t lddy, const float *y, int64_t ldy, int32_t act,
+                       const float *slope, int32_t M, int32_t N, float *dx, int64_t lddx,
+                       void *stream);
+
+/* y[N, M] = x[M, N]^T. */
+int blgnn_transpose(const float *x, int64_t ldx, int32_t M, int32_t N, float *y, int64_t ldy,
+                    void *stream);
+
+/* Gradient of blgnn_segment_reduce (model/layers_aggregation.py:16-19): every row of segment g
+ * receives dp[row_map ? row_map[g] : g] (/ max(count, 1) for MEAN); accumulate != 0 adds into dx
+ * (multi-scale readout: each layer's activation also carries the next layer's gradient). */
+int blgnn_segment_broadcast(const int32_t *seg, int32_t G, const float *dp, int64_t lddp,
+                            const int32_t *row_map, int32_t d, int32_t kind, float *dx,
+                            int64_t lddx, int32_t accumulate, void *stream);
+
+/* Gradient of blgnn_l2_normalize_rows: dz = (dzn - zn (zn . dzn)) / max(|z|, eps). */
+int blgnn_l2_normalize_backward(const float *z, int64_t ldz, const float *dzn, int64_t lddzn,
+                                int32_t M, int32_t d, float eps, float *dz, int64_t lddz,
+                                void *stream);
+
+/* Gradient of the pair scorer's row gather (model/layers_link_pred.py:56-61):
+ * dz[ids[b], :] += dcat[b, col0 : col0 + d]; dz zero-initialised by the caller (float atomics). */
+int blgnn_pair_scatter_add(const float *dcat, int64_t ldc, int32_t col0, const int64_t *ids,
+                           int32_t B, int32_t d, float *dz, int64_t lddz, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,7 +82,10 @@ def _node_embedding(x, info, sd, p, plain, flags):
         raise ValueError("Unknown node embedding layer type {}".format(t))
     x = ops.apply_act(x, act, pw)
     if _b(info["bn"]):
-        x = ops.batch_norm_eval(x, *_bn(sd, p + ".bn"))
+        if flags.get("train"):
+            x = ops.batch_norm_train(x, sd[p + ".bn.weight"], sd[p + ".bn.bias"])
+        else:
+            x = ops.batch_norm_eval(x, *_bn(sd, p + ".bn"))
     if _b(info["normalize"]):
         x = ops.l2_normalize(x)
     return x

@@ -124,6 +124,14 @@ def batch_norm_eval(x, weight, bias, running_mean, running_var, eps=1e-5):
     return (x - running_mean) / torch.sqrt(running_var + eps) * weight + bias
 
 
+def batch_norm_train(x, weight, bias, eps=1e-5):
+    """model/layers.py:56-57 in train mode (torch.nn.BatchNorm1d: batch mean, BIASED batch variance);
+    differentiable, used by the gradient-parity tests of the training step (src/train.py:177-182)."""
+    mean = x.mean(dim=0)
+    var = ((x - mean) ** 2).mean(dim=0)
+    return (x - mean) / torch.sqrt(var + eps) * weight + bias
+
+
 def l2_normalize(x, eps=1e-12):
     """torch.nn.functional.normalize(p=2, dim=1): model/layers.py:60-61,
     model/layers_link_pred.py:44, model/layers_gmn.py:75-76."""

@@ -1,0 +1,195 @@
+"""GPU parity of the training step (src/train.py:177-182): gradients produced by the
+libblgnn backward kernels against torch.autograd on the CPU oracle in fp64 -- op level, then the whole
+lower-level GIN model (loss, every parameter gradient, running statistics, a short Adam trajectory)."""
+
+import numpy as np
+import pytest
+import torch
+
+import blgnn
+import oracle
+from blgnn import autograd as ag
+from blgnn import ops
+from helpers import TOL, max_err, build, layer_specs, state_dict_cpu, plain_batch, oracle_flags
+
+pytestmark = pytest.mark.gpu
+
+
+def _leaf(t, device=None):
+    t = t.clone().to(device) if device else t.clone().double()
+    return t.requires_grad_(True)
+
+
+@pytest.mark.parametrize("M,K,N,act,grid", [(1000, 64, 64, "relu", True), (37001, 128, 128, "relu", True),
+                                            (37001, 128, 128, "identity", False), (513, 40, 128, "identity", False),
+                                            (300, 256, 1, "sigmoid", False), (64, 32, 16, "tanh", False)])
+def test_linear_backward(device, M, K, N, act, grid):
+    """``grid``: operands on a dyadic grid (every product and sum exact in fp32, pre-activations never 0), so the
+    relu mask is the same on both sides -- with random data a handful of the M*N pre-activations land within fp32
+    rounding of zero and the two masks differ there, which is the function's discontinuity, not a kernel error."""
+    g = torch.Generator().manual_seed(M + N)
+    if grid:
+        x = torch.randint(-4, 5, (M, K), generator=g).float() / 8
+        w = torch.randint(-4, 5, (N, K), generator=g).float() / 8
+        b = torch.randint(-4, 5, (N,), generator=g).float() / 8 + 1.0 / 128
+        dy = torch.randint(-4, 5, (M, N), generator=g).float() / 8
+    else:
+        x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+        dy = torch.randn(M, N, generator=g)
+    xr, wr, br = _leaf(x), _leaf(w), _leaf(b)
+    ref = oracle.ops.apply_act(xr @ wr.t() + br, act)
+    ref.backward(dy.double())
+    xd, wd, bd = _leaf(x, device), _leaf(w, device), _leaf(b, device)
+    got = ag.linear(xd, wd, bd, act)
+    got.backward(dy.to(device))
+    assert max_err(got, ref) < TOL
+    assert max_err(xd.grad, xr.grad) < TOL
+    assert max_err(wd.grad, wr.grad) < TOL         # reduction over M rows: scaled by the largest entry
+    assert max_err(bd.grad, br.grad) < TOL
+
+
+@pytest.mark.parametrize("M,N", [(37001, 128), (5, 64), (1025, 256)])
+def test_batch_norm_train_forward_backward_and_running_stats(device, M, N):
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, N, generator=g) * 2.0 + 0.5
+    dy = torch.randn(M, N, generator=g)
+    ref_bn = torch.nn.BatchNorm1d(N).double()
+    bn = torch.nn.BatchNorm1d(N).to(device)
+    with torch.no_grad():
+        ref_bn.weight.copy_(torch.rand(N, generator=g) + 0.5); ref_bn.bias.copy_(torch.randn(N, generator=g))
+        bn.weight.copy_(ref_bn.weight.float()); bn.bias.copy_(ref_bn.bias.float())
+    xr, xd = _leaf(x), _leaf(x, device)
+    ref = ref_bn(xr)
+    ref.backward(dy.double())
+    got = ag.batch_norm_train(xd, bn)
+    got.backward(dy.to(device))
+    assert max_err(got, ref) < TOL
+    assert max_err(xd.grad, xr.grad) < TOL
+    assert max_err(bn.weight.grad, ref_bn.weight.grad) < TOL
+    assert max_err(bn.bias.grad, ref_bn.bias.grad) < TOL
+    assert max_err(bn.running_mean, ref_bn.running_mean) < TOL
+    assert max_err(bn.running_var, ref_bn.running_var) < TOL
+    assert int(bn.num_batches_tracked) == 1
+
+
+def test_readout_normalise_gather_and_aggregation_backward(device):
+    ds = blgnn.make_synthetic(40, 200, seed=3, device=device)
+    pairs = ds.pair_gids[:32]
+    bd = blgnn.BatchData(pairs, ds, is_train=False)
+    m = bd.merge_data['merge']
+    n, G = m.x.shape[0], len(bd.merge_data['ind_list'])
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.randn(n, d, generator=g) for d in (64, 32)]
+    batch, ei = m.batch.cpu(), m.edge_index.cpu()
+    ids = torch.as_tensor(np.vectorize(bd.merge_data['gids_to_batch_ind'].get)(bd.batch_gids))
+    ids1, ids2 = ids[:, 0].contiguous(), ids[:, 1].contiguous()
+    w = torch.randn(ids.shape[0], 2 * 96, generator=g)
+
+    def chain(xs_, spmm, pool, norm, gather):
+        agg = [spmm(x) for x in xs_]
+        z = norm(pool(agg))
+        return (gather(z) * w.to(z.device).to(z.dtype)).sum()
+
+    xr = [_leaf(x) for x in xs]
+    ref = chain(xr,
+                lambda x: 1.25 * x + oracle.ops.scatter_add(x[ei[1]], ei[0], n),
+                lambda a: oracle.ops.node_aggregation(a, batch, G, "avg_pool"),
+                oracle.ops.l2_normalize,
+                lambda z: torch.cat([z[ids1], z[ids2]], dim=1))
+    ref.backward()
+    xd = [_leaf(x, device) for x in xs]
+    seg, csr = m.segments(), m.csr()
+    got = chain(xd,
+                lambda x: ag.spmm_sum(x, csr, 1.25),
+                lambda a: ag.segment_reduce_multi(seg, a, "mean"),
+                ag.l2_normalize,
+                lambda z: ag.pair_gather(z, ids1.to(device), ids2.to(device)))
+    got.backward()
+    assert max_err(got, ref) < TOL
+    for a, b in zip(xd, xr):
+        assert max_err(a.grad, b.grad) < TOL
+
+
+def _llgnn(device, D=64, n_mol=60, n_pairs=400, B=48, seed=5):
+    ds = blgnn.make_synthetic(n_mol, n_pairs, seed=seed, device=device)
+    flags = blgnn.make_flags("lower_level_gnn", lower_level_gnn_type="gin", D_lower=D, device=device)
+    model, data = build(flags, ds, seed=seed + 2)
+    specs = layer_specs(flags)
+    rng = np.random.default_rng(seed)
+    pairs = ds.pair_gids[rng.choice(len(ds.pair_gids), size=B, replace=False)]
+    bd = blgnn.BatchData(pairs, ds, sampled_gids=np.unique(pairs), is_train=True, rng=np.random.default_rng(seed))
+    ids = torch.as_tensor(np.vectorize(bd.merge_data['gids_to_batch_ind'].get)(bd.batch_gids))
+    return ds, flags, model, specs, bd, ids
+
+
+def _oracle_state(model):
+    """fp64 copy of the state_dict; parameters (not buffers) become autograd leaves"""
+    params = {k for k, _ in model.named_parameters()}
+    return {k: (v.double().requires_grad_(k in params) if v.is_floating_point() else v)
+            for k, v in state_dict_cpu(model).items()}
+
+
+def _oracle_loss(specs, sd, plain, of, labels):
+    acts = oracle.run_layers(specs, sd, plain, dict(of, train=True))
+    preds = acts[-1]
+    return torch.nn.functional.binary_cross_entropy(preds.view(-1), labels), acts
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_llgnn_training_step_gradients(device, D):
+    """loss.backward() of the LL-GNN model (src/train.py:177-182): loss, every activation and every parameter
+    gradient against fp64 autograd on the oracle; BatchNorm in train mode on both sides"""
+    ds, flags, model, specs, bd, ids = _llgnn(device, D)
+    of = oracle_flags(flags, ds)
+    sd = _oracle_state(model)
+    labels = bd.true_labels().cpu().double()
+    ref_loss, acts = _oracle_loss(specs, sd, plain_batch(bd, ds, torch.float64, with_pairs=ids), of, labels)
+    ref_loss.backward()
+
+    model.train()
+    loss = model(bd)
+    assert loss.dim() == 0 and loss.requires_grad
+    loss.backward()
+    assert max_err(loss, ref_loss) < TOL
+    for got, ref in zip(model.acts[1:-1], acts[1:]):
+        assert max_err(got, ref) < TOL
+    checked = 0
+    for name, p in model.named_parameters():
+        if name not in sd or not name.startswith("layers."):
+            continue
+        assert p.grad is not None, name
+        assert max_err(p.grad, sd[name].grad) < TOL, name
+        checked += 1
+    assert checked >= 5 * 6 + 4          # 5 GIN layers x (2 Linear x 2 + BN x 2) + the scorer's Linears
+    # a forward in eval mode still takes the fused path and uses the running statistics just updated
+    model.eval()
+    with torch.no_grad():
+        eval_loss = model(bd)
+    assert not eval_loss.requires_grad and torch.isfinite(eval_loss)
+
+
+def test_llgnn_adam_trajectory(device):
+    """ten optimizer steps on one batch: the loss follows the oracle's fp64 trajectory and goes down"""
+    ds, flags, model, specs, bd, ids = _llgnn(device, 64, seed=9)
+    of = oracle_flags(flags, ds)
+    sd = _oracle_state(model)
+    train_keys = [k for k, _ in model.named_parameters() if k.startswith("layers.")]
+    opt_ref = torch.optim.Adam([sd[k] for k in train_keys], lr=1e-3)
+    opt = torch.optim.Adam([p for k, p in model.named_parameters() if k.startswith("layers.")], lr=1e-3)
+    labels = bd.true_labels().cpu().double()
+    plain = plain_batch(bd, ds, torch.float64, with_pairs=ids)
+    model.train()
+    got, ref = [], []
+    for _ in range(10):
+        opt_ref.zero_grad()
+        rl, _a = _oracle_loss(specs, sd, plain, of, labels)
+        rl.backward()
+        opt_ref.step()
+        ref.append(float(rl))
+        opt.zero_grad()
+        loss = model(bd)
+        loss.backward()
+        opt.step()
+        got.append(float(loss))
+    assert got[-1] < got[0]
+    assert max(abs(a - b) for a, b in zip(got, ref)) < 1e-4, (got, ref)
