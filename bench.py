@@ -94,6 +94,9 @@ def parse():
                          "the interaction-level stream gets the rest.  0 = ordinary streams; -1 = the measured "
                          "optimum (20 at 1 GPU, 16 at 2, none from 4 GPUs on / for the large configs)")
     ap.add_argument("--readout-with-upper", action="store_true")
+    ap.add_argument("--no-fuse-readout", action="store_true",
+                    help="bi-level configs: a separate segment-reduce launch instead of the readout fused into the "
+                         "GIN layers' epilogues")
     ap.add_argument("--no-overlap", action="store_true",
                     help="replay the lower and upper graphs of a step back to back on one stream")
     ap.add_argument("--no-graph", action="store_true",
@@ -352,7 +355,8 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
     ds = blgnn.make_synthetic(n_drugs, n_pairs, shape=cfg["shape"], seed=seed, device=device)
     flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin",
                              higher_level_gnn_type="gat", D_lower=d, D_higher=d, device=device,
-                             batch_size=batch, feature_transform=transform)
+                             batch_size=batch, feature_transform=transform,
+                             fuse_readout=not args.no_fuse_readout)
     blgnn.set_flags(flags)
     torch.manual_seed(seed)
     data = blgnn.TrainData(ds, device=device)
@@ -456,6 +460,7 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
                       "pairs_per_step": pairs_per_step, "fresh_batch_every_step": True,
                       "hip_graph": bool(engine.use_graph), "two_stream_overlap": bool(engine.overlap),
                       "readout_with_upper": bool(engine.readout_with_upper),
+                      "fused_readout": bool(getattr(flags, "fuse_readout", False)) and engine.fused is None,
                       "lower_cus_per_xcd": engine.lower_cus_per_xcd, "fused_lower_stack": engine.fused is not None,
                       "exchange": ("first interaction layer's transform of the pooled rows [N_r, d+2]"
                                    if engine.exchange_transformed else "pooled rows [N_r, D_pool]"),

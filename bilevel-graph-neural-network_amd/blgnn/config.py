@@ -64,7 +64,8 @@ def make_flags(model="higher_level_gnn", dataset="drugbank", lower_level_gnn_typ
                higher_level_gnn_type="gat", D_lower=64, D_higher=64,
                lower_level_num_layers=None, higher_level_num_layers=3, batch_size=None,
                device="cuda:0", node_aggr=None, bn=True, gnn_normalize=False,
-               gat_softmax_group="src", d_init=64, feature_transform="f16x3", multi_edge_node_model="gat"):
+               gat_softmax_group="src", d_init=64, feature_transform="f16x3", multi_edge_node_model="gat",
+               fuse_readout=True):
     """Reproduce the flag values and layer list of src/config.py for ``model``.
     Defaults are the reference's (config.py:96,126-131,180,237-238)."""
     if model not in MODELS:
@@ -155,6 +156,9 @@ def make_flags(model="higher_level_gnn", dataset="drugbank", lower_level_gnn_typ
     #   "bf16x6": bf16 matrix cores, operands split in three pieces (six MFMAs), fp32-equivalent accuracy
     #   "f32":    exact-f32 MFMA (v_mfma_f32_32x32x2_f32), 2.7x the matrix-core time of bf16x6
     f.feature_transform = feature_transform
+    # node -> graph readout accumulated by the producing GIN layers' epilogues instead of a separate
+    # segment-reduce launch (blgnn/layers.py ReadoutPlan; not a reference flag)
+    f.fuse_readout = fuse_readout
     if last_lower is not None:
         f.last_lower_lyr_num = last_lower
     for i, s in enumerate(layers):

@@ -295,6 +295,7 @@ class BiLevelEngine(object):
             with torch.no_grad():
                 m = self.model
                 m.acts = [self.lower_batch.merge_data['merge'].x]
+                m._readout_direct = True            # the readout layer runs here or at the head of upper()
                 for layer in (self.lower_layers if readout else self.lower_layers[:-1]):
                     m.acts.append(layer(m.acts[-1], self.lower_batch, m))
                 if not readout:

@@ -39,6 +39,7 @@ class GraphData(object):
         self.num_graphs = num_graphs
         self._csr = None
         self._seg = None
+        self._batch32 = None
         # compact form of x when it is a concatenation of one-hot blocks: int8 [n, 8] value indices and the
         # first column of every block (+ total width); the first lower layer can read these instead of x
         self.codes = None
@@ -68,6 +69,12 @@ class GraphData(object):
         if self._seg is None:
             self._seg = ops.segments_from_batch(self.batch, self.num_graphs)
         return self._seg
+
+    def row_graph(self):
+        """The sorted batch vector as int32 (what the fused-readout epilogue indexes by)."""
+        if self._batch32 is None:
+            self._batch32 = self.batch.to(torch.int32).contiguous()
+        return self._batch32
 
     def contiguous(self):
         return self

@@ -62,6 +62,69 @@ class GCNConv(nn.Module):
         _glorot(self.weight)
 
 
+class ReadoutPlan(object):
+    """Node -> graph readout fused into the layers that produce the pooled activations (north_star: "with the
+    node readout in layers_aggregation.py fused in").  Built by the first lower GIN layer of a forward when the
+    layers that follow it in ``model.layers`` are GIN layers of one width and then a segment-pool readout
+    (model/layers_aggregation.py:32-41): every pooled layer adds its rows into its column slice of ``dest`` from
+    the kernel epilogue (or, when its kernel has no such epilogue, by one segment-reduce launch), and the readout
+    layer finds its result already there."""
+
+    def __init__(self, batch_data, agg, convs, pooled_convs, seg, row_graph, dest):
+        self.batch, self.agg, self.convs = batch_data, agg, convs
+        self.seg, self.row_graph, self.dest = seg, row_graph, dest
+        n = convs[0].out_dim
+        self.cols = {id(c): i * n for i, c in enumerate(pooled_convs)}
+        self.kind = agg.agg_func.kind
+        self.done = set()
+
+    def pool_for(self, layer):
+        c = self.cols.get(id(layer))
+        if c is None:
+            return None
+        return (self.row_graph, self.seg, self.dest[:, c:c + layer.out_dim], self.kind)
+
+    def complete(self):
+        return len(self.done) == len(self.cols)
+
+
+def _build_readout_plan(first, model, batch_data):
+    from .layers_aggregation import NodeAggregationPairs, _SegmentPool
+    if not getattr(FLAGS, "fuse_readout", True) or getattr(FLAGS, "feature_transform", "f16x3") != "f16x3":
+        return None
+    if 'gmn' in FLAGS.model or first.out_dim not in (128, 256):
+        return None
+    layers = list(model.layers)
+    i = next((k for k, l in enumerate(layers) if l is first), None)
+    if i is None:
+        return None
+    convs, j = [], i
+    while j < len(layers) and isinstance(layers[j], NodeEmbedding):
+        l = layers[j]
+        if l.type != 'gin' or l.higher_level or l.normalize or l.out_dim != first.out_dim:
+            return None
+        convs.append(l)
+        j += 1
+    if j >= len(layers) or not isinstance(layers[j], NodeAggregationPairs):
+        return None
+    agg = layers[j]
+    if not isinstance(agg.agg_func, _SegmentPool):
+        return None
+    pooled = convs if agg.concat_multi_scale else convs[-1:]
+    if len(pooled) > 8:
+        return None
+    g = batch_data.merge_data['merge']
+    seg = g.segments()
+    G, width = seg.numel() - 1, first.out_dim * len(pooled)
+    dest = None
+    if getattr(model, "_readout_direct", False) and hasattr(agg, "readout_destination"):
+        dest = agg.readout_destination(batch_data, width)          # the init_x rows of the batch graphs
+    if dest is None:
+        dest = torch.empty((G, width), dtype=torch.float32, device=g.x.device)
+    dest.zero_()
+    return ReadoutPlan(batch_data, agg, convs, pooled, seg, g.row_graph(), dest)
+
+
 class NodeEmbedding(nn.Module):
     def __init__(self, type, in_dim, out_dim, act, bn, normalize, higher_level=False,
                  use_edge_attr=None):
@@ -105,6 +168,15 @@ class NodeEmbedding(nn.Module):
         slopes = prelu_slopes(self._cache, "prelu", self.act, self.out_dim)
         scale, shift = bn_affine(self._cache, "bn", self.bn)
         with torch.no_grad():
+            plan = pool = None
+            if self.type == 'gin' and not self.higher_level:
+                if model.acts is not None and len(model.acts) == 1:      # first layer of a forward
+                    model._readout_plan = _build_readout_plan(self, model, batch_data) if out is None else None
+                plan = getattr(model, "_readout_plan", None)
+                if plan is not None and (plan.batch is not batch_data or out is not None):
+                    plan = model._readout_plan = None
+                pool = plan.pool_for(self) if plan is not None else None
+            fused_pool = False
             if self.type == 'gin':
                 lin1, lin2 = self.conv.nn[0], self.conv.nn[2]
                 w1 = self._cache.get("w1", lambda w: w.t().contiguous(), lin1.weight)
@@ -122,13 +194,15 @@ class NodeEmbedding(nn.Module):
                     w2p = self._cache.get("w2h", lambda w: ops.pack_weight_h3(w.t().contiguous()), lin2.weight)
                     x = ops.gin_layer_h3_codes(csr, codes, g.code_offsets, w1p, lin1.bias, w2p, lin2.bias,
                                                self.out_dim, eps=eps, act=act, act_param=slopes, bn_scale=scale,
-                                               bn_shift=shift, out=out)
+                                               bn_shift=shift, out=out, pool=pool)
+                    fused_pool = True
                 elif transform == "f16x3" and ops.gin_layer_h3_supported(csr, ins, ins.shape[1], self.out_dim):
                     # dense transforms on the fp16 matrix cores at fp32 accuracy (scaled two-piece split)
                     w1p = self._cache.get("w1h", lambda w: ops.pack_weight_h3(w.t().contiguous()), lin1.weight)
                     w2p = self._cache.get("w2h", lambda w: ops.pack_weight_h3(w.t().contiguous()), lin2.weight)
                     x = ops.gin_layer_h3(csr, ins, w1p, lin1.bias, w2p, lin2.bias, self.out_dim, eps=eps,
-                                         act=act, act_param=slopes, bn_scale=scale, bn_shift=shift, out=out)
+                                         act=act, act_param=slopes, bn_scale=scale, bn_shift=shift, out=out, pool=pool)
+                    fused_pool = True
                 elif transform in ("bf16x6", "f16x3") and \
                         ops.gin_layer_x6_supported(csr, ins, ins.shape[1], self.out_dim):
                     # dense transforms on the bf16 matrix cores at fp32 accuracy (three-piece split)
@@ -155,11 +229,14 @@ class NodeEmbedding(nn.Module):
                 edge_weight = getattr(batch_data.merge_data['merge'], "edge_attr", None)
                 x = ops.gcn_conv(csr, ins, self.conv.weight, self.conv.bias, edge_weight,
                                  act=act, act_param=slopes, bn_scale=scale, bn_shift=shift, out=out)
+            if pool is not None:
+                if not fused_pool:          # this layer's kernel has no readout epilogue: one segment-reduce launch
+                    ops.segment_reduce(plan.seg, x, plan.kind, out=pool[2])
+                plan.done.add(id(self))
             model.store_layer_output(self, x)
             if self.normalize:
                 x = ops.l2_normalize_rows(x)
         return x
-
 
     def _forward_train(self, ins, batch_data, model, out=None):
         """Train mode (src/train.py:177-182 runs backward through this layer): the same arithmetic as

@@ -63,6 +63,15 @@ class NodeAggregationPairs(nn.Module):
             else:
                 xs = [ins]
             return ag.segment_reduce_multi(seg, xs, self.agg_func.kind)
+        plan = getattr(model, "_readout_plan", None)
+        if plan is not None and plan.agg is self and plan.batch is batch_data and not pair_batch:
+            model._readout_plan = None
+            if plan.complete():
+                # the pooled rows were accumulated by the producing layers' epilogues (layers.ReadoutPlan)
+                if out is None or out.data_ptr() == plan.dest.data_ptr():
+                    return plan.dest
+                out.copy_(plan.dest)
+                return out
         with torch.no_grad():
             if self.concat_multi_scale:
                 if 'gmn' not in FLAGS.model:
@@ -104,6 +113,17 @@ class NodeAggregation(NodeAggregationPairs):
     def __init__(self, style, is_last_layer, **kwargs):
         super(NodeAggregation, self).__init__(style, **kwargs)
         self.is_last_layer = is_last_layer
+
+    def readout_destination(self, batch_data, width):
+        """The slice of the interaction graph's init_x this batch's pooled rows go to, when the batch graphs are a
+        contiguous run of interaction rows (else None)."""
+        if not FLAGS.higher_level_layers:
+            return None
+        init_x = batch_data.interaction_combo_nxgraph.init_x
+        rng = batch_data.interaction_row_range() if hasattr(batch_data, "interaction_row_range") else None
+        if rng is None or not isinstance(init_x, torch.Tensor) or init_x.shape[1] != width:
+            return None
+        return init_x[rng[0]:rng[1]]
 
     def forward(self, x, batch_data, model, pair_batch=False):
         if not FLAGS.higher_level_layers:

@@ -61,7 +61,10 @@ class Model(nn.Module):
 
     def forward(self, batch_data):
         self.acts = [batch_data.merge_data['merge'].x]
-        for layer in self._selected():
+        selected = self._selected()
+        # the fused readout may write straight into init_x only when the readout layer is part of this slice
+        self._readout_direct = any(hasattr(l, "readout_destination") for l in selected)
+        for layer in selected:
             self.acts.append(layer(self.acts[-1], batch_data, self))
         return self.acts[-1]
 

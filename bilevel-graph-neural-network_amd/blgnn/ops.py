@@ -184,16 +184,30 @@ def gin_layer_h3_supported(csr, x, K, N):
             and x.data_ptr() % 16 == 0 and csr.nnz < 12 * max(csr.n, 1))
 
 
+def _pool_args(pool, n, N):
+    """``pool`` = (row_graph int32[n], seg int32[G+1], pooled [G, N] view, kind) -> the five readout arguments."""
+    if pool is None:
+        return None, None, None, 0, 0
+    row_graph, seg, pooled, kind = pool
+    pp, ldp = _mat(pooled, "pooled")
+    if pooled.shape != (seg.numel() - 1, N) or row_graph.numel() != n:
+        raise ValueError("blgnn: fused readout expects pooled [G, %d] and one graph id per row" % N)
+    return (_vec(row_graph, "row_graph", torch.int32, False), _vec(seg, "seg", torch.int32, False), pp, ldp,
+            REDUCE_MEAN if kind == "mean" else REDUCE_SUM)
+
+
 def gin_layer_h3(csr, x, w1_packed, b1, w2_packed, b2, N, eps=0.0, act="identity", act_param=None,
-                 bn_scale=None, bn_shift=None, out=None):
-    """blgnn_gin_layer with both GEMMs on the fp16 matrix cores at fp32 accuracy (f16x3)."""
+                 bn_scale=None, bn_shift=None, out=None, pool=None):
+    """blgnn_gin_layer with both GEMMs on the fp16 matrix cores at fp32 accuracy (f16x3).  ``pool``: fused
+    node -> graph readout of the result into a zero-initialised [G, N] view (see ``_pool_args``)."""
     xp, ldx = _mat(x, "x")
     n, K = x.shape
     y = _out(out, n, N, x)
     yp, ldy = _mat(y, "out")
     call("blgnn_gin_layer_h3", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, xp, ldx, n, K,
          w1_packed.data_ptr(), _vec(b1, "b1"), w2_packed.data_ptr(), _vec(b2, "b2"), N, float(eps), _act(act),
-         _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), yp, ldy, _stream())
+         _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), yp, ldy,
+         *_pool_args(pool, n, N), _stream())
     return y
 
 
@@ -204,7 +218,7 @@ def gin_layer_h3_codes_supported(csr, codes, offsets, N):
 
 
 def gin_layer_h3_codes(csr, codes, offsets, w1_packed, b1, w2_packed, b2, N, eps=0.0, act="identity", act_param=None,
-                       bn_scale=None, bn_shift=None, out=None):
+                       bn_scale=None, bn_shift=None, out=None, pool=None):
     """blgnn_gin_layer_h3 on categorical input: ``codes`` int8 [n, 8] (one value index per attribute),
     ``offsets`` = first one-hot column of every attribute + the total width."""
     import ctypes
@@ -218,7 +232,7 @@ def gin_layer_h3_codes(csr, codes, offsets, w1_packed, b1, w2_packed, b2, N, eps
     call("blgnn_gin_layer_h3_codes", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, codes.data_ptr(), offs,
          len(offsets) - 1, n, w1_packed.data_ptr(), _vec(b1, "b1"), w2_packed.data_ptr(), _vec(b2, "b2"), N,
          float(eps), _act(act), _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"),
-         yp, ldy, _stream())
+         yp, ldy, *_pool_args(pool, n, N), _stream())
     return y
 
 

@@ -71,6 +71,10 @@ struct GinH3Args {
     const uint2 *codes;
     uint8_t code_off[8];                     // first column of every attribute's one-hot block
     int32_t n_attr;
+    // fused node -> graph readout (model/layers_aggregation.py:16-19,32-41): pool[row_graph[i], :] += y[i, :] * w
+    const int32_t *row_graph, *seg;          // graph of every row (sorted) / graph row ranges [G + 1]
+    float *pool; int64_t ldp;                // zero-initialised by the caller; nullptr = no readout
+    int32_t pool_mean;                       // w = 1 / max(rows of the graph, 1), else 1
 };
 
 // columns 4 l .. 4 l + 3 of the one-hot row of an atom
@@ -151,7 +155,7 @@ __device__ __forceinline__ void gemm_h3(f32x16 (&acc0)[MT], f32x16 (&acc1)[MT], 
 // workgroup per CU: every weight fragment serves two row tiles, i.e. 8.2 KB of weight traffic per row
 // against 24.6 KB for the bf16x6 kernel's 32-row tiles -- at d = 256 that traffic (L2 -> CU operand
 // delivery, ~18 B/clk/CU), not the matrix cores, sets the time of these layers.
-template <int LG, int ACT, int XBM, bool CODES = false, int N = 128>
+template <int LG, int ACT, int XBM, bool CODES = false, int N = 128, bool POOL = false>
 __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_layer_h3(const GinH3Args A) {
     constexpr int MT = XBM / 32;
     constexpr int NW = N / 32, NTH = 64 * NW;               // waves / threads per workgroup
@@ -178,6 +182,8 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
     int *cs = rp + XBM + 4;                                 // [HCOLS]
     float *ainv = reinterpret_cast<float *>(cs + HCOLS);    // [XBM] 1 / row scale of the aggregate
     unsigned *hmax = reinterpret_cast<unsigned *>(ainv + XBM);   // [XBM] row maxima of the hidden tile (float bits)
+    int *rgraph = reinterpret_cast<int *>(hmax + XBM);           // [XBM] graph of every tile row (fused readout)
+    float *rweight = reinterpret_cast<float *>(rgraph + XBM);    // [XBM] readout weight of every tile row
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
     const int fi = lane & 31, fh = lane >> 5;
     const int sub = lane / LG, l = lane % LG;
@@ -221,6 +227,13 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
     }
     if (threadIdx.x <= XBM) rp[threadIdx.x] = rpv;
     if (threadIdx.x < XBM) hmax[threadIdx.x] = 0u;
+    if (POOL && threadIdx.x >= NTH - XBM) {          // the last XBM threads: their other start-up loads are fewest
+        const int m = threadIdx.x - (NTH - XBM);
+        const int r = m0 + m;
+        const int g = A.row_graph[r < A.n ? r : A.n - 1];
+        rgraph[m] = g;
+        rweight[m] = A.pool_mean ? 1.f / (float)max(A.seg[g + 1] - A.seg[g], 1) : 1.f;
+    }
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         const int m = (p * NW + wid) * RPW + sub;
@@ -407,6 +420,39 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
         if (vec_out) *reinterpret_cast<float4 *>(dst) = v;
         else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
     }
+    // ---- (4) fused readout: per-graph column sums of the staged tile, one atomic per (graph, column) and tile.
+    // Rows are sorted by graph, so a tile touches few graphs (DrugBank: 27 atoms per molecule, ~2 per tile) and a
+    // graph spans few tiles; with <= 2 contributions per graph the sum does not depend on their order.
+    if (POOL) {
+        // every thread: one column, RPT consecutive rows (all waves take part).  The staged values are requested at
+        // once; graph boundaries come from one ballot, so the serial part is RPT adds and a few scalar branches.
+        constexpr int RPT = XBM * N / NTH;                                   // 16 (N = 128) / 32 (N = 256)
+        const int c = threadIdx.x % N;
+        const int mb = __builtin_amdgcn_readfirstlane((threadIdx.x / N) * RPT);      // wave-uniform
+        const int rows = min(A.n - m0 - mb, RPT);
+        if (rows > 0) {
+            float v[RPT];
+#pragma unroll
+            for (int m = 0; m < RPT; ++m) v[m] = Ys[(mb + m) * LDO + c];
+            // bit m: row m starts another graph than row m - 1
+            const int lr = lane & (RPT - 1);
+            const int gl = rgraph[mb + lr], gp = rgraph[mb + (lr > 0 ? lr - 1 : 0)];
+            const unsigned starts = (unsigned)__ballot(lr > 0 && lr < rows && gl != gp) & (RPT == 32 ? 0xffffffffu : ((1u << (RPT & 31)) - 1u));
+            auto flush = [&](int first_row, float sum) {
+                const int g = __builtin_amdgcn_readfirstlane(rgraph[mb + first_row]);
+                const float w = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rweight[mb + first_row])));
+                unsafeAtomicAdd(A.pool + (int64_t)g * A.ldp + c, sum * w);
+            };
+            int first = 0;
+            float sum = 0.f;
+#pragma unroll
+            for (int m = 0; m < RPT; ++m) {
+                if (m > 0 && ((starts >> m) & 1u)) { flush(first, sum); first = m; sum = 0.f; }
+                if (m < rows) sum += v[m];
+            }
+            flush(first, sum);
+        }
+    }
 }
 
 static size_t h3_lds_bytes(int K, int Kp, int XBM, int N = 128) {
@@ -414,22 +460,28 @@ static size_t h3_lds_bytes(int K, int Kp, int XBM, int N = 128) {
     if ((size_t)XBM * (N + 4) * 4 > r0) r0 = (size_t)XBM * (N + 4) * 4;
     size_t r1 = (size_t)XBM * K * 4;
     if ((size_t)2 * XBM * (N * 2 + 16) > r1) r1 = (size_t)2 * XBM * (N * 2 + 16);
-    return r0 + r1 + sizeof(int) * (XBM + 4 + HCOLS) + sizeof(float) * 2 * XBM;
+    return r0 + r1 + sizeof(int) * (XBM + 4 + HCOLS) + sizeof(float) * 2 * XBM + (sizeof(int) + sizeof(float)) * XBM;
 }
 
-template <int LG, int ACT, int XBM, bool CODES = false, int N = 128>
-static int launch_h3_rows(const GinH3Args &A, hipStream_t s) {
+template <int LG, int ACT, int XBM, bool CODES, int N, bool POOL>
+static int launch_h3_inst(const GinH3Args &A, hipStream_t s) {
     static size_t declared = 0;
     const size_t bytes = h3_lds_bytes(A.K, A.Kp, XBM, N);
     if (bytes > declared && bytes > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gin_layer_h3<LG, ACT, XBM, CODES, N>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gin_layer_h3<LG, ACT, XBM, CODES, N, POOL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
             return fail(BLGNN_ERR_LAUNCH, "gin_layer_h3: cannot raise the dynamic LDS limit to %zu bytes", bytes);
         declared = bytes;
     }
     const int blocks = (A.n + XBM - 1) / XBM;
-    hipLaunchKernelGGL((k_gin_layer_h3<LG, ACT, XBM, CODES, N>), dim3(blocks), dim3(N * 2), bytes, s, A);
+    hipLaunchKernelGGL((k_gin_layer_h3<LG, ACT, XBM, CODES, N, POOL>), dim3(blocks), dim3(N * 2), bytes, s, A);
     return launch_status("gin_layer_h3");
+}
+
+// the fused-readout epilogue is its own instantiation: the plain layer keeps its register allocation
+template <int LG, int ACT, int XBM, bool CODES = false, int N = 128>
+static int launch_h3_rows(const GinH3Args &A, hipStream_t s) {
+    return A.pool ? launch_h3_inst<LG, ACT, XBM, CODES, N, true>(A, s) : launch_h3_inst<LG, ACT, XBM, CODES, N, false>(A, s);
 }
 
 template <int LG, int ACT>
@@ -507,8 +559,11 @@ extern "C" int blgnn_gin_layer_h3(const int32_t *rowptr, const int32_t *col, int
                                   int64_t ldx, int32_t n, int32_t K, const void *w1_packed, const float *b1,
                                   const void *w2_packed, const float *b2, int32_t N, float eps, int32_t act,
                                   const float *act_param, const float *bn_scale, const float *bn_shift,
-                                  float *y, int64_t ldy, void *stream) {
+                                  float *y, int64_t ldy, const int32_t *row_graph, const int32_t *seg,
+                                  float *pooled, int64_t ldp, int32_t pool_kind, void *stream) {
     BLGNN_CHECK_ARG(n >= 0 && K > 0 && N > 0 && nnz >= 0, "gin_layer_h3: bad sizes");
+    BLGNN_CHECK_ARG(!pooled || (row_graph && seg && ldp >= N && (pool_kind == BLGNN_REDUCE_SUM || pool_kind == BLGNN_REDUCE_MEAN)),
+                    "gin_layer_h3: fused readout needs row_graph, seg, ldp >= N and a reduce kind");
     if (n == 0) return BLGNN_OK;
     BLGNN_CHECK_ARG(rowptr && (col || nnz == 0) && x && w1_packed && w2_packed && y, "gin_layer_h3: null pointer");
     BLGNN_CHECK_ARG(ldx >= K && ldy >= N, "gin_layer_h3: leading dimension too small");
@@ -525,6 +580,7 @@ extern "C" int blgnn_gin_layer_h3(const int32_t *rowptr, const int32_t *col, int
     A.epi = Epilogue{b2, act_param, bn_scale, bn_shift, act};
     A.y = y; A.ldy = ldy;
     A.codes = nullptr; A.n_attr = 0;
+    A.row_graph = row_graph; A.seg = seg; A.pool = pooled; A.ldp = ldp; A.pool_mean = pool_kind == BLGNN_REDUCE_MEAN;
     hipStream_t s = (hipStream_t)stream;
     const int k4 = K / 4;
     if (N == 256) {
@@ -541,7 +597,10 @@ extern "C" int blgnn_gin_layer_h3_codes(const int32_t *rowptr, const int32_t *co
                                         const void *w1_packed, const float *b1, const void *w2_packed,
                                         const float *b2, int32_t N, float eps, int32_t act, const float *act_param,
                                         const float *bn_scale, const float *bn_shift, float *y, int64_t ldy,
-                                        void *stream) {
+                                        const int32_t *row_graph, const int32_t *seg, float *pooled, int64_t ldp,
+                                        int32_t pool_kind, void *stream) {
+    BLGNN_CHECK_ARG(!pooled || (row_graph && seg && ldp >= N && (pool_kind == BLGNN_REDUCE_SUM || pool_kind == BLGNN_REDUCE_MEAN)),
+                    "gin_layer_h3_codes: fused readout needs row_graph, seg, ldp >= N and a reduce kind");
     BLGNN_CHECK_ARG(n >= 0 && N > 0 && nnz >= 0 && num_attr >= 1 && num_attr <= 8 && code_offsets_host,
                     "gin_layer_h3_codes: bad sizes");
     if (n == 0) return BLGNN_OK;
@@ -559,6 +618,7 @@ extern "C" int blgnn_gin_layer_h3_codes(const int32_t *rowptr, const int32_t *co
     A.epi = Epilogue{b2, act_param, bn_scale, bn_shift, act};
     A.y = y; A.ldy = ldy;
     A.codes = reinterpret_cast<const uint2 *>(codes); A.n_attr = num_attr;
+    A.row_graph = row_graph; A.seg = seg; A.pool = pooled; A.ldp = ldp; A.pool_mean = pool_kind == BLGNN_REDUCE_MEAN;
     for (int a = 0; a < 8; ++a) {
         const int o = a < num_attr ? code_offsets_host[a] : 0;
         BLGNN_CHECK_ARG(o >= 0 && o < 256, "gin_layer_h3_codes: attribute offset out of range");

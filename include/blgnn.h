@@ -138,8 +138,15 @@ int blgnn_gin_layer_x6(const int32_t *rowptr, const int32_t *col, int64_t nnz,
  * exact powers of two).  Half the matrix-core work and two thirds of the operand bytes of the
  * bf16x6 variant; 64-row tiles.  w*_packed = blgnn_pack_weight_h3 images
  * (blgnn_packed_weight_h3_elems fp16 elements each, 16-byte aligned: 16-byte header holding
- * 1/scale, then [2 pieces][Kp/8][N][8]).  N == 128, K % 4 == 0, K <= 128, else
- * BLGNN_ERR_UNSUPPORTED (use blgnn_gin_layer_x6). */
+ * 1/scale, then [2 pieces][Kp/8][N][8]).  N in {128, 256}, K % 4 == 0, K <= N, else
+ * BLGNN_ERR_UNSUPPORTED (use blgnn_gin_layer_x6).
+ * Fused node -> graph readout (model/layers_aggregation.py:16-19,32-41; north_star "with the node
+ * readout fused in"): with pooled != NULL every tile also adds its rows' column sums into
+ *   pooled[row_graph[i], 0:N] += y[i, :] * (pool_kind == MEAN ? 1 / max(|graph|, 1) : 1)
+ * (row_graph = the sorted batch vector as int32[n], seg = graph row ranges int32[G+1], pooled
+ * ZERO-INITIALISED by the caller, typically a column slice of the multi-scale readout buffer).
+ * One hardware float atomic per (graph, column, tile): a graph covered by <= 2 tiles sums in an
+ * order-independent way; larger ones may differ in the last bit between runs.  pooled == NULL: off. */
 int64_t blgnn_packed_weight_h3_elems(int32_t K, int32_t N);
 int blgnn_pack_weight_h3(const float *w, int64_t ldw, int32_t K, int32_t N, void *out,
                          void *stream);
@@ -148,7 +155,9 @@ int blgnn_gin_layer_h3(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                        const void *w1_packed, const float *b1, const void *w2_packed,
                        const float *b2, int32_t N, float eps, int32_t act,
                        const float *act_param, const float *bn_scale,
-                       const float *bn_shift, float *y, int64_t ldy, void *stream);
+                       const float *bn_shift, float *y, int64_t ldy, const int32_t *row_graph,
+                       const int32_t *seg, float *pooled, int64_t ldp, int32_t pool_kind,
+                       void *stream);
 
 /* blgnn_gin_layer_h3 for the FIRST lower layer with categorical input: instead of the one-hot rows
  * x[n, F_in] (utils/data/representation_node_feat.py:86-97: one block per attribute, one 1 per block)
@@ -162,7 +171,8 @@ int blgnn_gin_layer_h3_codes(const int32_t *rowptr, const int32_t *col, int64_t 
                              const float *b1, const void *w2_packed, const float *b2,
                              int32_t N, float eps, int32_t act, const float *act_param,
                              const float *bn_scale, const float *bn_shift, float *y,
-                             int64_t ldy, void *stream);
+                             int64_t ldy, const int32_t *row_graph, const int32_t *seg,
+                             float *pooled, int64_t ldp, int32_t pool_kind, void *stream);
 
 /* The whole lower level in ONE launch: num_layers (<= 8) stacked GIN NodeEmbedding layers
  * (model/layers.py:26-31,51-57) + the node -> graph readout of every layer that is pooled

@@ -186,7 +186,8 @@ def test_engine_graph_replay_and_two_stream_overlap_match_eager(device):
     from blgnn.engine import BiLevelEngine
     ds = blgnn.make_synthetic(200, 1500, seed=21, device=device)
     flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin",
-                             higher_level_gnn_type="gat", D_lower=64, D_higher=64, device=device)
+                             higher_level_gnn_type="gat", D_lower=64, D_higher=64, device=device,
+                             fuse_readout=False)   # bitwise comparisons: no float atomics in the readout
     model, data = build(flags, ds, seed=5)
     lower = blgnn.BatchData(all_molecule_pairs(ds.molecules.gids), ds, is_train=False, ignore_pairs=True)
     g = ds.interaction_combo_nxgraph
@@ -287,7 +288,8 @@ def test_engine_exchange_after_first_transform_is_bitwise_the_replicated_forward
     from blgnn.engine import BiLevelEngine
     ds = blgnn.make_synthetic(150, 1100, seed=23, device=device)
     flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin",
-                             higher_level_gnn_type="gat", D_lower=128, D_higher=128, device=device)
+                             higher_level_gnn_type="gat", D_lower=128, D_higher=128, device=device,
+                             fuse_readout=False)   # bitwise comparisons: no float atomics in the readout
     model, data = build(flags, ds, seed=7)
     lower = blgnn.BatchData(all_molecule_pairs(ds.molecules.gids), ds, is_train=False, ignore_pairs=True)
     g = ds.interaction_combo_nxgraph
@@ -312,7 +314,8 @@ def test_engine_follows_weight_updates_after_capture(device):
     from blgnn.engine import BiLevelEngine
     ds = blgnn.make_synthetic(120, 900, seed=22, device=device)
     flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin",
-                             higher_level_gnn_type="gat", D_lower=128, D_higher=128, device=device)
+                             higher_level_gnn_type="gat", D_lower=128, D_higher=128, device=device,
+                             fuse_readout=False)   # bitwise comparisons: no float atomics in the readout
     model, data = build(flags, ds, seed=6)
     lower = blgnn.BatchData(all_molecule_pairs(ds.molecules.gids), ds, is_train=False, ignore_pairs=True)
     g = ds.interaction_combo_nxgraph
@@ -355,3 +358,43 @@ def test_readout_styles_forward(device, node_aggr):
         model.acts.append(layer(model.acts[-1], bd, model))
     for got, ref in zip(model.acts[1:], acts[1:]):
         assert max_err(got, ref) < TOL
+
+
+def test_fused_readout_is_the_default_and_matches_the_separate_launch(device):
+    """north_star "with the node readout fused in": by default the lower GIN layers accumulate the multi-scale
+    readout from their epilogues (no segment-reduce launch); == the separate launch to fp32 rounding, direct
+    into init_x, and the engine's captured graphs replay it"""
+    from blgnn.engine import BiLevelEngine
+    ds = blgnn.make_synthetic(120, 600, seed=6, device=device)
+    outs = {}
+    for fuse in (True, False):
+        flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin",
+                                 higher_level_gnn_type="gat", D_lower=128, D_higher=128, device=device,
+                                 fuse_readout=fuse)
+        model, data = build(flags, ds, seed=7)
+        calls = []
+        orig = blgnn.ops.segment_reduce_multi
+        blgnn.ops.segment_reduce_multi = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            preds, bd = bilevel_forward(model, data, _pairs(ds, 64))
+        finally:
+            blgnn.ops.segment_reduce_multi = orig
+        assert (len(calls) == 0) == fuse
+        outs[fuse] = (preds.clone(), ds.interaction_combo_nxgraph.init_x.clone())
+    assert max_err(outs[True][1], outs[False][1]) < 1e-6
+    assert max_err(outs[True][0], outs[False][0]) < 1e-6
+    # engine: eager and captured replays of the fused-readout sweep agree to rounding (atomics may reorder)
+    flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin", higher_level_gnn_type="gat",
+                             D_lower=128, D_higher=128, device=device, fuse_readout=True)
+    model, data = build(flags, ds, seed=7)
+    lower = blgnn.BatchData(all_molecule_pairs(ds.molecules.gids), ds, is_train=False, ignore_pairs=True)
+    g = ds.interaction_combo_nxgraph
+    upper = blgnn.BatchData(_pairs(ds, 64), ds, is_train=False)
+    with BiLevelEngine(model, lower, upper, g, use_graph=False) as e0:
+        ref = e0.eager_step(0).clone()
+    with BiLevelEngine(model, lower, upper, g, use_graph=True, overlap=True) as eng:
+        eng.capture()
+        for _ in range(3):
+            out = eng.step(0)
+        eng.synchronize()
+        assert max_err(out, ref) < 1e-6

@@ -160,6 +160,48 @@ def test_gin_layer_f16x3(device, K, act, N):
     assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + N:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("N,kind,sizes", [(128, "mean", None), (128, "sum", None), (256, "mean", None),
+                                          (128, "mean", [1, 70, 3, 129, 33, 2, 64])])
+def test_gin_layer_f16x3_fused_readout(device, N, kind, sizes):
+    """north_star "with the node readout fused in": the layer's epilogue adds every tile's per-graph column sums
+    into a column slice of the pooled buffer; == scatter_mean / scatter_add of the layer's own output (fp32
+    rounding apart: the mean weight is applied per tile) and == the oracle's readout of the oracle's layer.
+    ``sizes``: graphs of 1 row, graphs spanning three and five tiles"""
+    if sizes is None:
+        ei, batch, n = molecule_graph(57, 21)
+    else:
+        rng = np.random.default_rng(1)
+        edges, batch, n = [], [], 0
+        for gi, sz in enumerate(sizes):
+            for a in range(sz - 1):
+                edges += [(n + a, n + a + 1), (n + a + 1, n + a)]
+            batch += [gi] * sz
+            n += sz
+        ei = torch.as_tensor(sorted(edges), dtype=torch.int64).t().contiguous()
+        batch = torch.as_tensor(batch, dtype=torch.int64)
+    G = int(batch.max()) + 1
+    K = N
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(n, K, generator=g)
+    w1, b1 = torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g) * 0.1
+    w2, b2 = torch.randn(N, N, generator=g) / N ** 0.5, torch.randn(N, generator=g) * 0.1
+    D = lambda t: t.double()
+    ref = oracle.apply_act(oracle.gin_conv(D(x), ei, D(w1), D(b1), D(w2), D(b2), "relu", eps=0.0), "relu")
+    ref_pool = oracle.node_aggregation([ref], batch, G, "avg_pool" if kind == "mean" else "sum")
+    dv = lambda t: t.to(device)
+    csr = ops.csr_from_edge_index(dv(ei), n)
+    seg = ops.segments_from_batch(dv(batch), G)
+    w1p, w2p = ops.pack_weight_h3(dv(w1.t().contiguous())), ops.pack_weight_h3(dv(w2.t().contiguous()))
+    pooled = torch.zeros(G, 3 * N, device=device)
+    got = ops.gin_layer_h3(csr, dv(x), w1p, dv(b1), w2p, dv(b2), N, act="relu",
+                           pool=(dv(batch).to(torch.int32), seg, pooled[:, N:2 * N], kind))
+    plain = ops.gin_layer_h3(csr, dv(x), w1p, dv(b1), w2p, dv(b2), N, act="relu")
+    assert torch.equal(got, plain)                                  # the layer's own output is untouched
+    assert float(pooled[:, :N].abs().max()) == 0.0 and float(pooled[:, 2 * N:].abs().max()) == 0.0
+    assert max_err(pooled[:, N:2 * N], ref_pool) < TOL
+    assert max_err(pooled[:, N:2 * N], ops.segment_reduce(seg, got, kind)) < 1e-6
+
+
 @pytest.mark.parametrize("act", ["relu", "identity"])
 def test_gin_layer_f16x3_categorical_input(device, act):
     """first lower layer fed with 8 bytes of attribute value indices per atom == the same layer fed with the
