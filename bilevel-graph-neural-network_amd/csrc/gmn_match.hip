@@ -26,11 +26,9 @@ k_gmn_match(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__r
 
     // `parts` workgroups share one pair (interleaved query rows): when the matrix-core kernel has taken
     // the small pairs, the few big ones left would otherwise each serialise on a single workgroup
-    for (int item = blockIdx.x; item < num_pairs * parts; item += gridDim.x) {
-        const int pair = item / parts, part = item - pair * parts;
+    auto process = [&](int pair, int part) {
         const int s0 = seg[2 * pair], s1 = seg[2 * pair + 1], s2 = seg[2 * pair + 2];
         const int n1 = s1 - s0, n2 = s2 - s1, nt = n1 + n2;
-        if (n1 <= skip_small && n2 <= skip_small) continue;   // the matrix-core kernel owns this pair
         const bool staged = (int64_t)nt * lds_ld <= (int64_t)lds_floats;
         __syncthreads();                                   // previous pair done with LDS
         if (staged) {
@@ -130,77 +128,145 @@ k_gmn_match(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__r
                 }
             }
         }
+    };
+    if (skip_small < 0) {
+        for (int item = blockIdx.x; item < num_pairs * parts; item += gridDim.x) process(item / parts, item % parts);
+    } else {
+        // the matrix-core kernels own every pair up to skip_small nodes per graph: 64 pairs are inspected with one
+        // vector load of their segment offsets and only the (rare) larger ones are processed
+        // (`parts` consecutive workgroups inspect the same 64 pairs and share each large one's query rows)
+        const int group = blockIdx.x / parts, part = blockIdx.x - group * parts, groups = gridDim.x / parts;
+        for (int base = group * WAVE; base < num_pairs; base += groups * WAVE) {
+            const int pr = base + lane;
+            bool need = false;
+            if (pr < num_pairs) {
+                const int a = seg[2 * pr + 1] - seg[2 * pr], b = seg[2 * pr + 2] - seg[2 * pr + 1];
+                need = a > skip_small || b > skip_small;
+            }
+            unsigned long long mask = __ballot(need);
+            while (mask) {
+                const int q = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                process(base + q, part);
+            }
+        }
     }
 }
 
 
-// ---- matrix-core variant for pairs with both graphs <= 64 nodes (95 % of DrugBank / DrugCombo pairs) --------
-// The work of a pair is three small GEMMs -- S = G1 G2^T over the D features, U1 = A G2, U2 = A'^T-free
-// form A' G1 -- so it runs on v_mfma_f32_32x32x2_f32 (exact f32; 6 n1 n2 D flop is nothing for the matrix
-// cores, the scalar kernel above spends 25x the roofline time on it).  One 256-thread workgroup per pair,
-// features streamed in 64-column chunks (next chunk prefetched into registers under the MFMAs):
-//   pass 1  S_raw += G1c G2c^T, the four waves split the chunk's k range; row norms on the side;
-//           partials summed in a fixed order, scaled to cosines;
-//   softmax over rows (A, n1 x n2) and over columns (A', stored n2 x n1), padded entries zero;
-//   pass 2  per chunk: waves 0-1  U1c = G1c - A G2c,  waves 2-3  U2c = G2c - A' G1c, written straight out.
+// ---- matrix-core kernels ---------------------------------------------------------------------------------------------------
+// The work of a pair is three small GEMMs -- S = G1 G2^T over the D features, U1 = G1 - A G2, U2 = G2 - A' G1 -- so it
+// runs on v_mfma_f32_32x32x2_f32 (exact f32; 6 n1 n2 D flop is nothing for the matrix cores, the scalar kernel above
+// spends 25x the roofline time on it).  Cosines lie in [-1, 1], so the softmaxes need no running maximum:
+//     E_ij = exp(cos_ij)   (0 outside n1 x n2),   A = diag(1 / rowsum E) E,   A' = diag(1 / colsum E) E^T
+// E is formed ONCE in LDS; pass 2 feeds it to the matrix cores as it is (row-major for U1, read transposed for U2) and the
+// 1 / sum factors scale the 16 results of a lane at store time -- no exp, no attention matrix, no VALU work inside the
+// MFMA loops.  Features stream in 64-column chunks, two chunks in flight per thread (the chunk loads are what a pair waits
+// for: ~20 barriers per pair against ~1 us of matrix-core time), pass 2's first chunks requested before the softmax phase.
+//   k_gmn_match_mfma      both graphs <= 64 nodes (95 % of DrugBank / DrugCombo pairs): 256 threads, two workgroups per CU;
+//                         pass 1 splits a chunk's k range over the four waves (partials summed in a fixed order)
+//   k_gmn_match_mfma_big  a graph of 65 .. 128 nodes (5 % of the pairs, 9 % of the atoms -- the scalar kernel spent more time
+//                         on them than on the other 95 %): 512 threads, one workgroup per CU, E (128 x 128) resident;
+//                         pass 1: the <= 16 tiles of S, two per wave; pass 2: one U1 and one U2 tile per wave and chunk
 typedef float f32x16m __attribute__((ext_vector_type(16)));
-constexpr int MM = 64;              // max nodes per graph
+typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
+constexpr int MM = 64;              // max nodes per graph (small kernel)
 constexpr int MCH = 64;             // feature chunk
-constexpr int MLD = 65;             // LDS row stride (floats)
-constexpr int MREG = MM * MLD;      // floats per LDS region
+constexpr int MLD = 65;             // LDS row stride (floats) of a chunk / of the small kernel's S
+constexpr int MREG = MM * MLD;      // floats per LDS region (small kernel)
+constexpr int BM = 128;             // max nodes per graph (big kernel)
+constexpr int BLD = 129;            // LDS row stride of the big kernel's E
+constexpr int BIG_PPW = 8;          // pairs inspected per workgroup of the big kernel (most are not big: the
+                                    // hardware's workgroup dispatch balances the few that are)
+
+// chunk c of both graphs of a pair -> 8 float4 per thread (rows lrow + RS p of graph 1 for p < 4, of graph 2 for p >= 4)
+template <int RS>
+__device__ __forceinline__ void match_fetch(float4 (&pre)[8], __amdgpu_buffer_rsrc_t RX, unsigned xvoff, int lrow, int n1, int n2,
+                                            int64_t ldx, int c) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int r = lrow + RS * (p & 3);
+        const bool first = p < 4;
+        const bool live = first ? r < n1 : r < n2;
+        const unsigned soff = (unsigned)(((first ? 0 : n1) + RS * (p & 3)) * ldx + c * MCH) * 4u;
+        const u32x4m v = __builtin_amdgcn_raw_buffer_load_b128(RX, xvoff, soff, 0);
+        const float4 f = __builtin_bit_cast(float4, v);
+        pre[p] = live ? f : f4_zero();
+    }
+}
+
+template <int RS>
+__device__ __forceinline__ void match_park(const float4 (&pre)[8], float *G1c, float *G2c, int lrow, int lc4) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        float *dst = (p < 4 ? G1c : G2c) + (lrow + RS * (p & 3)) * MLD + 4 * lc4;
+        dst[0] = pre[p].x; dst[1] = pre[p].y; dst[2] = pre[p].z; dst[3] = pre[p].w;
+    }
+}
+
+__device__ __forceinline__ void match_norms(float (&nsq)[8], const float4 (&pre)[8]) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        nsq[p] = fmaf(pre[p].x, pre[p].x, nsq[p]); nsq[p] = fmaf(pre[p].y, pre[p].y, nsq[p]);
+        nsq[p] = fmaf(pre[p].z, pre[p].z, nsq[p]); nsq[p] = fmaf(pre[p].w, pre[p].w, nsq[p]);
+    }
+}
+
+// U tile of pass 2: o = E-operand x partner chunk, then own chunk - o * (1 / sum) -> global.
+//   TRANS = false: rows of graph 1 (E row-major),  TRANS = true: rows of graph 2 (E read transposed)
+template <bool TRANS, int ELD>
+__device__ __forceinline__ void match_u_tile(const float *E, const float *isum, const float *own, const float *partner, int rt, int ct,
+                                             int kmax, int nrows, int row0, int64_t ldu, int c, __amdgpu_buffer_rsrc_t RU,
+                                             unsigned uvoff, int fi, int fh) {
+    const float *er = TRANS ? E + fh * ELD + 32 * rt + fi : E + (32 * rt + fi) * ELD + fh;
+    const float *br = partner + fh * MLD + 32 * ct + fi;
+    f32x16m o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    for (int k = 0; k < kmax; k += 2)       // (requesting eight operand pairs ahead by hand measured slower: 314 vs 276 us)
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(TRANS ? er[k * ELD] : er[k], br[k * MLD], o, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rc = 32 * rt + (r & 3) + 8 * (r >> 2);                  // + 4 fh = row inside the graph
+        const unsigned soff = (unsigned)((row0 + rc) * ldu + c * MCH + 32 * ct) * 4u;
+        if (rc + 4 * fh < nrows)
+            __builtin_amdgcn_raw_buffer_store_b32(
+                __builtin_bit_cast(unsigned int, own[(rc + 4 * fh) * MLD + 32 * ct + fi] - o[r] * isum[rc + 4 * fh]), RU, uvoff,
+                soff, 0);
+    }
+}
 
 __global__ void __launch_bounds__(256, 2)
 k_gmn_match_mfma(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__restrict__ x, int64_t ldx,
                  float *__restrict__ u, int64_t ldu, int32_t d) {
     extern __shared__ float4 smem4[];
-    float *R0 = reinterpret_cast<float *>(smem4);       // pass 1: G1 chunk | partial 2 ; later A' (n2 x n1)
+    float *R0 = reinterpret_cast<float *>(smem4);       // pass 1: G1 chunk | partial 2
     float *R1 = R0 + MREG;                              // pass 1: G2 chunk | partial 3 ; pass 2: G2 chunk
-    float *R2 = R1 + MREG;                              // partial 0 -> S ; pass 2: G1 chunk
-    float *R3 = R2 + MREG;                              // partial 1 ; later A (n1 x n2)
-    float *inv = R3 + MREG;                             // [2 * MM] 1 / max(|row|, eps)
+    float *R2 = R1 + MREG;                              // partial 0 -> E
+    float *R3 = R2 + MREG;                              // partial 1 ; pass 2: G1 chunk
+    float *inv = R3 + MREG;                             // [2 MM] 1 / max(|row|, eps)
+    float *ril = inv + 2 * MM, *cil = ril + MM;         // 1 / row sums, 1 / column sums of E
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fi = lane & 31, fh = lane >> 5;
     const int lrow = tid >> 4, lc4 = tid & 15;          // chunk loads: 16 threads x 16 B per row, 16 rows per pass
     const int nch = d / MCH;
-    // Buffer addressing: one per-thread VGPR offset + a wave-uniform SGPR offset per access, so the
-    // 8 chunk loads and 32 result stores of a thread cost no address registers (with flat 64-bit
-    // addresses hipcc keeps one address pair per access live across the chunk loop and spills).
-    // Rows past the end of x read as zero (bounds-checked descriptor).
-    const int total_rows = seg[2 * num_pairs];
-    typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t RX = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(x), 0, (int)(((int64_t)(total_rows - 1) * ldx + d) * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t RU = __builtin_amdgcn_make_buffer_rsrc(
-        u, 0, (int)(((int64_t)(total_rows - 1) * ldu + d) * 4), 0x00020000);
+    // Buffer addressing: one per-thread VGPR offset + a wave-uniform SGPR offset per access, so the chunk loads and the
+    // 32 result stores of a thread cost no address registers.  The descriptors are built PER PAIR (base = the pair's
+    // first row): offsets stay far below 2^32 bytes whatever the size of x / u (d = 512 at 657 k atoms is 5.4 GB), and
+    // rows past the pair read as zero.
     const unsigned xvoff = (unsigned)(lrow * ldx + 4 * lc4) * 4u;
     const unsigned uvoff = (unsigned)(4 * fh * ldu + fi) * 4u;
 
     for (int pair = blockIdx.x; pair < num_pairs; pair += gridDim.x) {
         const int s0 = seg[2 * pair], s1 = seg[2 * pair + 1], s2 = seg[2 * pair + 2];
         const int n1 = s1 - s0, n2 = s2 - s1;
-        if (n1 > MM || n2 > MM || (n1 == 0 && n2 == 0)) continue;          // big pairs: scalar kernel
+        if (n1 > MM || n2 > MM || (n1 == 0 && n2 == 0)) continue;          // bigger pairs: k_gmn_match_mfma_big
         const int TM = (n1 + 31) >> 5, TN = (n2 + 31) >> 5;
-        // rows of the two 64-row slabs this thread loads: slab row = lrow + 16 p, p < 4 (G1) and p < 4 (G2)
-        float4 pre[8];
-        auto fetch = [&](int c) {
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int r = lrow + 16 * (p & 3);
-                const bool first = p < 4;
-                const bool live = first ? r < n1 : r < n2;
-                const unsigned soff = (unsigned)(((first ? s0 : s1) + 16 * (p & 3)) * ldx + c * MCH) * 4u;
-                const u32x4m v = __builtin_amdgcn_raw_buffer_load_b128(RX, xvoff, soff, 0);
-                const float4 f = __builtin_bit_cast(float4, v);
-                pre[p] = live ? f : f4_zero();
-            }
-        };
-        auto park = [&](float *G1c, float *G2c) {
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                float *dst = (p < 4 ? G1c : G2c) + (lrow + 16 * (p & 3)) * MLD + 4 * lc4;
-                dst[0] = pre[p].x; dst[1] = pre[p].y; dst[2] = pre[p].z; dst[3] = pre[p].w;
-            }
-        };
+        const __amdgpu_buffer_rsrc_t RX = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(x + (int64_t)s0 * ldx), 0, (int)(((int64_t)(n1 + n2 - 1) * ldx + d) * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t RU = __builtin_amdgcn_make_buffer_rsrc(
+            u + (int64_t)s0 * ldu, 0, (int)(((int64_t)(n1 + n2 - 1) * ldu + d) * 4), 0x00020000);
+        float4 preA[8];
 
         // ---- pass 1: raw similarities + squared norms -----------------------------------------------------
         f32x16m acc[2][2];
@@ -213,17 +279,7 @@ k_gmn_match_mfma(const int32_t *__restrict__ seg, int32_t num_pairs, const float
         float nsq[8];
 #pragma unroll
         for (int p = 0; p < 8; ++p) nsq[p] = 0.f;
-        fetch(0);
-        for (int c = 0; c < nch; ++c) {
-            __syncthreads();                                   // previous chunk / previous pair done with R0, R1
-            park(R0, R1);
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                nsq[p] = fmaf(pre[p].x, pre[p].x, nsq[p]); nsq[p] = fmaf(pre[p].y, pre[p].y, nsq[p]);
-                nsq[p] = fmaf(pre[p].z, pre[p].z, nsq[p]); nsq[p] = fmaf(pre[p].w, pre[p].w, nsq[p]);
-            }
-            if (c + 1 < nch) fetch(c + 1);
-            __syncthreads();
+        auto s_chunk = [&]() {
             const int kb = wid * (MCH / 4);                    // this wave's 16 k of the chunk
             if (TM == 1 && TN == 1) {                          // wave-uniform: one 32 x 32 tile
 #pragma unroll
@@ -245,7 +301,17 @@ k_gmn_match_mfma(const int32_t *__restrict__ seg, int32_t num_pairs, const float
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
                 }
             }
+        };
+        match_fetch<16>(preA, RX, xvoff, lrow, n1, n2, ldx, 0);
+        for (int c = 0; c < nch; ++c) {
+            __syncthreads();                                   // previous chunk / previous pair done with R0, R1
+            match_park<16>(preA, R0, R1, lrow, lc4);
+            match_norms(nsq, preA);
+            if (c + 1 < nch) match_fetch<16>(preA, RX, xvoff, lrow, n1, n2, ldx, c + 1);
+            __syncthreads();
+            s_chunk();
         }
+        match_fetch<16>(preA, RX, xvoff, lrow, n1, n2, ldx, 0);      // pass 2's first chunk: in flight during the softmax phase
         __syncthreads();                                       // all waves done reading the last chunk
         // partial S of wave w -> region (w == 0 ? R2 : w == 1 ? R3 : w == 2 ? R0 : R1); norms -> inv
         {
@@ -268,71 +334,181 @@ k_gmn_match_mfma(const int32_t *__restrict__ seg, int32_t num_pairs, const float
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < MM * MM; idx += 256) {       // cosine similarity, fixed summation order
+        for (int idx = tid; idx < MM * MM; idx += 256) {       // E = exp(cosine), fixed summation order of the partials
             const int i = idx >> 6, j = idx & 63;
             const int o = i * MLD + j;
-            R2[o] = (((R2[o] + R3[o]) + R0[o]) + R1[o]) * inv[i] * inv[MM + j];
+            const float cs = (((R2[o] + R3[o]) + R0[o]) + R1[o]) * inv[i] * inv[MM + j];
+            R2[o] = (i < n1 && j < n2) ? expf(cs) : 0.f;
         }
         __syncthreads();
-        // ---- softmax over rows (A -> R3) and over columns (A' -> R0, stored [j][i]) -----------------------------
-        if (tid < MM) {
-            const int i = tid;
-            float m = -INFINITY, l = 0.f;
-            if (i < n1) {
-                for (int j = 0; j < n2; ++j) m = fmaxf(m, R2[i * MLD + j]);
-                for (int j = 0; j < n2; ++j) l += expf(R2[i * MLD + j] - m);
-            }
-            const float il = (i < n1 && n2 > 0) ? 1.f / l : 0.f;
-            for (int j = 0; j < MM; ++j)
-                R3[i * MLD + j] = (i < n1 && j < n2) ? expf(R2[i * MLD + j] - m) * il : 0.f;
-        } else if (tid < 2 * MM) {
+        if (tid < MM) {                                        // 1 / row sums
+            float l = 0.f;
+            for (int j = 0; j < n2; ++j) l += R2[tid * MLD + j];
+            ril[tid] = (tid < n1 && n2 > 0) ? 1.f / l : 0.f;
+        } else if (tid < 2 * MM) {                             // 1 / column sums
             const int j = tid - MM;
-            float m = -INFINITY, l = 0.f;
-            if (j < n2) {
-                for (int i = 0; i < n1; ++i) m = fmaxf(m, R2[i * MLD + j]);
-                for (int i = 0; i < n1; ++i) l += expf(R2[i * MLD + j] - m);
-            }
-            const float il = (j < n2 && n1 > 0) ? 1.f / l : 0.f;
-            for (int i = 0; i < MM; ++i)
-                R0[j * MLD + i] = (j < n2 && i < n1) ? expf(R2[i * MLD + j] - m) * il : 0.f;
+            float l = 0.f;
+            for (int i = 0; i < n1; ++i) l += R2[i * MLD + j];
+            cil[j] = (j < n2 && n1 > 0) ? 1.f / l : 0.f;
         }
         // ---- pass 2: U1 = G1 - A G2 (waves 0, 1), U2 = G2 - A' G1 (waves 2, 3), 32 columns per wave ---------------
-        fetch(0);
         const bool second = wid >= 2;
         const int ct = wid & 1;
-        const float *Am = second ? R0 : R3;                    // [rows of the output graph][partner rows]
-        const int TR = second ? TN : TM, TK = second ? TM : TN;
-        const int nrows = second ? n2 : n1;
-        const int64_t gbase = second ? s1 : s0;
+        auto u_chunk = [&](int c) {
+            if (!second) {
+#pragma unroll 1
+                for (int i = 0; i < 2; ++i)
+                    if (i < TM) match_u_tile<false, MLD>(R2, ril, R3, R1, i, ct, 32 * TN, n1, 0, ldu, c, RU, uvoff, fi, fh);
+            } else {
+#pragma unroll 1
+                for (int i = 0; i < 2; ++i)
+                    if (i < TN) match_u_tile<true, MLD>(R2, cil, R1, R3, i, ct, 32 * TM, n2, n1, ldu, c, RU, uvoff, fi, fh);
+            }
+        };
         for (int c = 0; c < nch; ++c) {
-            __syncthreads();                                   // softmax written / previous chunk consumed
-            park(R2, R1);                                      // G1 chunk -> R2, G2 chunk -> R1
-            if (c + 1 < nch) fetch(c + 1);
+            __syncthreads();                                   // sums written / previous chunk consumed
+            match_park<16>(preA, R3, R1, lrow, lc4);           // G1 chunk -> R3, G2 chunk -> R1
+            if (c + 1 < nch) match_fetch<16>(preA, RX, xvoff, lrow, n1, n2, ldx, c + 1);
             __syncthreads();
-            const float *Bm = second ? R2 : R1;                // partner graph's chunk
-            const float *Gm = second ? R1 : R2;                // own chunk
+            u_chunk(c);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(512)
+k_gmn_match_mfma_big(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__restrict__ x, int64_t ldx,
+                     float *__restrict__ u, int64_t ldu, int32_t d) {
+    extern __shared__ float4 smem4[];
+    float *E = reinterpret_cast<float *>(smem4);        // [BM][BLD]
+    float *G1c = E + BM * BLD;                          // [BM][MLD]
+    float *G2c = G1c + BM * MLD;                        // [BM][MLD]
+    float *inv = G2c + BM * MLD;                        // [2 BM] 1 / max(|row|, eps)
+    float *ril = inv + 2 * BM, *cil = ril + BM;         // 1 / row sums, 1 / column sums of E
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fi = lane & 31, fh = lane >> 5;
+    const int lrow = tid >> 4, lc4 = tid & 15;          // chunk loads: 16 threads x 16 B per row, 32 rows per pass
+    const int nch = d / MCH;
+    const unsigned xvoff = (unsigned)(lrow * ldx + 4 * lc4) * 4u;
+    const unsigned uvoff = (unsigned)(4 * fh * ldu + fi) * 4u;
+
+    // which of this workgroup's BIG_PPW pairs are big: one vector load of their segment offsets
+    unsigned todo;
+    {
+        const int q = lane < BIG_PPW ? lane : 0;
+        const int pr = blockIdx.x + q * gridDim.x;
+        bool big = false;
+        if (lane < BIG_PPW && pr < num_pairs) {
+            const int a = seg[2 * pr + 1] - seg[2 * pr], b = seg[2 * pr + 2] - seg[2 * pr + 1];
+            big = (a > MM || b > MM) && a <= BM && b <= BM;
+        }
+        todo = (unsigned)__ballot(big);
+    }
+    while (todo) {
+        const int q = __builtin_ctz(todo);
+        todo &= todo - 1;
+        const int pair = blockIdx.x + q * gridDim.x;
+        const int s0 = seg[2 * pair], s1 = seg[2 * pair + 1], s2 = seg[2 * pair + 2];
+        const int n1 = s1 - s0, n2 = s2 - s1;
+        const int TM = (n1 + 31) >> 5, TN = (n2 + 31) >> 5;
+        const __amdgpu_buffer_rsrc_t RX = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(x + (int64_t)s0 * ldx), 0, (int)(((int64_t)(n1 + n2 - 1) * ldx + d) * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t RU = __builtin_amdgcn_make_buffer_rsrc(
+            u + (int64_t)s0 * ldu, 0, (int)(((int64_t)(n1 + n2 - 1) * ldu + d) * 4), 0x00020000);
+        float4 preA[8], preB[8];
+
+        // ---- pass 1: raw similarities (tiles wid and wid + 8 of the 4 x 4 grid) + squared norms ---------------------
+        f32x16m acc[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (i >= TR) continue;
-                f32x16m o;
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[r] = 0.f;
-                for (int k = 0; k < 32 * TK; k += 2) {
-                    const float a = Am[(32 * i + fi) * MLD + k + fh];
-                    const float b = Bm[(k + fh) * MLD + 32 * ct + fi];
-                    o = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, o, 0, 0, 0);
-                }
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        float nsq[8];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rc = 32 * i + (r & 3) + 8 * (r >> 2);      // + 4 fh = row inside the graph
-                    const unsigned soff = (unsigned)((gbase + rc) * ldu + c * MCH + 32 * ct) * 4u;
-                    if (rc + 4 * fh < nrows)
-                        __builtin_amdgcn_raw_buffer_store_b32(
-                            __builtin_bit_cast(unsigned int, Gm[(rc + 4 * fh) * MLD + 32 * ct + fi] - o[r]), RU, uvoff,
-                            soff, 0);
-                }
+        for (int p = 0; p < 8; ++p) nsq[p] = 0.f;
+        auto s_chunk = [&]() {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int tile = wid + 8 * t, ti = tile >> 2, tj = tile & 3;
+                if (ti >= TM || tj >= TN) continue;            // wave-uniform
+                const float *ar = G1c + (32 * ti + fi) * MLD + fh, *br = G2c + (32 * tj + fi) * MLD + fh;
+#pragma unroll 8
+                for (int k = 0; k < MCH; k += 2)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[k], br[k], acc[t], 0, 0, 0);
+            }
+        };
+        match_fetch<32>(preA, RX, xvoff, lrow, n1, n2, ldx, 0);
+        if (nch > 1) match_fetch<32>(preB, RX, xvoff, lrow, n1, n2, ldx, 1);
+        for (int c = 0; c < nch; c += 2) {
+            __syncthreads();                                   // previous chunk / previous pair done with the chunks
+            match_park<32>(preA, G1c, G2c, lrow, lc4);
+            match_norms(nsq, preA);
+            if (c + 2 < nch) match_fetch<32>(preA, RX, xvoff, lrow, n1, n2, ldx, c + 2);
+            __syncthreads();
+            s_chunk();
+            if (c + 1 < nch) {
+                __syncthreads();
+                match_park<32>(preB, G1c, G2c, lrow, lc4);
+                match_norms(nsq, preB);
+                if (c + 3 < nch) match_fetch<32>(preB, RX, xvoff, lrow, n1, n2, ldx, c + 3);
+                __syncthreads();
+                s_chunk();
             }
         }
+        match_fetch<32>(preA, RX, xvoff, lrow, n1, n2, ldx, 0);      // pass 2's first two chunks
+        if (nch > 1) match_fetch<32>(preB, RX, xvoff, lrow, n1, n2, ldx, 1);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            float v = nsq[p];
+            v += __shfl_xor(v, 1, WAVE); v += __shfl_xor(v, 2, WAVE);
+            v += __shfl_xor(v, 4, WAVE); v += __shfl_xor(v, 8, WAVE);
+            if (lc4 == 0) inv[(p < 4 ? 0 : BM) + lrow + 32 * (p & 3)] = 1.f / fmaxf(sqrtf(v), 1e-12f);
+        }
+        __syncthreads();
+        // E = exp(cosine) inside n1 x n2, 0 outside
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int tile = wid + 8 * t, ti = tile >> 2, tj = tile & 3;
+            const int col = 32 * tj + fi;
+            const float ic = inv[BM + col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const bool in = ti < TM && tj < TN && row < n1 && col < n2;
+                E[row * BLD + col] = in ? expf(acc[t][r] * inv[row] * ic) : 0.f;
+            }
+        }
+        __syncthreads();
+        if (tid < BM) {                                        // 1 / row sums
+            float l = 0.f;
+            for (int j = 0; j < n2; ++j) l += E[tid * BLD + j];
+            ril[tid] = (tid < n1 && n2 > 0) ? 1.f / l : 0.f;
+        } else if (tid < 2 * BM) {                             // 1 / column sums
+            const int j = tid - BM;
+            float l = 0.f;
+            for (int i = 0; i < n1; ++i) l += E[i * BLD + j];
+            cil[j] = (j < n2 && n1 > 0) ? 1.f / l : 0.f;
+        }
+        // ---- pass 2: per chunk one U1 tile (rows 32 (wid >> 1), columns 32 (wid & 1)) and one U2 tile per wave ----
+        const int rt = wid >> 1, ct = wid & 1;
+        auto u_chunk = [&](int c) {
+            if (rt < TM) match_u_tile<false, BLD>(E, ril, G1c, G2c, rt, ct, 32 * TN, n1, 0, ldu, c, RU, uvoff, fi, fh);
+            if (rt < TN) match_u_tile<true, BLD>(E, cil, G2c, G1c, rt, ct, 32 * TM, n2, n1, ldu, c, RU, uvoff, fi, fh);
+        };
+        for (int c = 0; c < nch; c += 2) {
+            __syncthreads();                                   // sums written / previous chunk consumed
+            match_park<32>(preA, G1c, G2c, lrow, lc4);
+            if (c + 2 < nch) match_fetch<32>(preA, RX, xvoff, lrow, n1, n2, ldx, c + 2);
+            __syncthreads();
+            u_chunk(c);
+            if (c + 1 < nch) {
+                __syncthreads();
+                match_park<32>(preB, G1c, G2c, lrow, lc4);
+                if (c + 3 < nch) match_fetch<32>(preB, RX, xvoff, lrow, n1, n2, ldx, c + 3);
+                __syncthreads();
+                u_chunk(c + 1);
+            }
+        }
+        __syncthreads();                                       // E / chunks free for the next pair
     }
 }
 
@@ -359,7 +535,7 @@ extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const floa
     int skip_small = -1;
     if (d % MCH == 0) {                                    // matrix-core kernel for pairs up to 64 x 64 nodes
         static bool declared = false;
-        const int mbytes = (4 * MREG + 2 * MM) * (int)sizeof(float);
+        const int mbytes = (4 * MREG + 4 * MM) * (int)sizeof(float);
         if (!declared) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gmn_match_mfma),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, mbytes) != hipSuccess)
@@ -368,9 +544,22 @@ extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const floa
         }
         const int mblocks = num_pairs < 256 * 8 ? num_pairs : 256 * 8;
         hipLaunchKernelGGL(k_gmn_match_mfma, dim3(mblocks), dim3(256), mbytes, s, seg, num_pairs, x, ldx, u, ldu, d);
-        const int rc = launch_status("gmn_match");
+        int rc = launch_status("gmn_match");
         if (rc != BLGNN_OK) return rc;
-        skip_small = MM;
+        // pairs with a graph of 65 .. 128 nodes: one 512-thread workgroup each, S resident in LDS
+        static bool declared_big = false;
+        const int bbytes = (BM * BLD + 2 * BM * MLD + 4 * BM) * (int)sizeof(float);
+        if (!declared_big) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gmn_match_mfma_big),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bbytes) != hipSuccess)
+                return fail(BLGNN_ERR_LAUNCH, "gmn_match: cannot raise the dynamic LDS limit");
+            declared_big = true;
+        }
+        hipLaunchKernelGGL(k_gmn_match_mfma_big, dim3((num_pairs + BIG_PPW - 1) / BIG_PPW), dim3(512), bbytes, s, seg, num_pairs,
+                           x, ldx, u, ldu, d);
+        rc = launch_status("gmn_match");
+        if (rc != BLGNN_OK) return rc;
+        skip_small = BM;
     }
     size_t want = (size_t)128 * (d + 4) * sizeof(float);
     if (want < 64 * 1024) want = 64 * 1024;
@@ -379,7 +568,7 @@ extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const floa
     const int lds_floats = lds_bytes / 4;
     const int threads = lds_bytes > 80 * 1024 ? 512 : 256;
     const int parts = skip_small >= 0 ? 8 : 1;
-    const int64_t items = (int64_t)num_pairs * parts;
+    const int64_t items = skip_small >= 0 ? (int64_t)(num_pairs + WAVE - 1) / WAVE * parts : (int64_t)num_pairs;
     const int blocks = (int)(items < 256 * 8 ? items : 256 * 8);
     const int ch = (d / 4 + WAVE - 1) / WAVE;
 #define BLGNN_GMN_LAUNCH(CH_)                                                                       \

@@ -586,7 +586,11 @@ def test_segment_reduce_multi_scale(device):
                                      (256, [32, 32, 33, 31, 64, 64, 1, 64, 64, 1]),     # tile edges of the matrix-core kernel
                                      (192, [28, 40, 0, 17, 9, 0]),                      # empty graphs on either side
                                      (72, [20, 30, 44, 12]),                            # d % 64 != 0: scalar kernel
-                                     (128, [28] * 64)])
+                                     (128, [28] * 64),
+                                     # 65 .. 128 nodes: the LDS-resident matrix-core kernel (tile edges, one side small,
+                                     # several per workgroup stride, next to small and > 128 pairs)
+                                     (256, [65, 3, 128, 128, 97, 64, 1, 96, 30, 30, 129, 20, 100, 33]),
+                                     (64, [70, 90] * 9 + [10, 12])])
 def test_gmn_match(device, d, sizes):
     off = np.concatenate([[0], np.cumsum(sizes)])
     ind = [(int(off[i]), int(off[i + 1])) for i in range(len(sizes))]
