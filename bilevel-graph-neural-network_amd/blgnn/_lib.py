@@ -77,6 +77,8 @@ SIGNATURES = {
     "blgnn_segment_broadcast": [_p, _i32, _p, _i64, _p, _i32, _i32, _p, _i64, _i32, _p],
     "blgnn_l2_normalize_backward": [_p, _i64, _p, _i64, _i32, _i32, _f32, _p, _i64, _p],
     "blgnn_pair_scatter_add": [_p, _i64, _i32, _p, _i32, _i32, _p, _i64, _p],
+    "blgnn_gat_backward_scores": [_p, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _p, _p, _p],
+    "blgnn_gat_backward_features": [_p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _p, _i64, _p],
 }
 LIBRARY_SYMBOLS = ["blgnn_version", "blgnn_last_error", "blgnn_device_count", "blgnn_packed_weight_x6_elems",
                    "blgnn_packed_weight_h3_elems", "blgnn_packed_weight_h3g_elems",

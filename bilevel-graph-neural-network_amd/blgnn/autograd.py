@@ -12,16 +12,19 @@ every arithmetic step of both directions is a kernel behind the C ABI:
   readout            blgnn_segment_broadcast per pooled activation
   pair scorer        blgnn_l2_normalize_backward, blgnn_pair_scatter_add
 
-Scope: the lower-level GIN model ("lower_level_gnn": NodeEmbedding gin x L -> multi-scale
-readout -> mlp_concat pair scorer -> BCE), with relu / identity / sigmoid / tanh activations.  GAT / GCN / GMN
-layers raise NotImplementedError in training mode.
+  GATConv            blgnn_gat_backward_scores / _features (+ blgnn_linear for datt, dW, dx)
+
+Scope: GIN and GAT NodeEmbedding layers on either level, the avg_pool / sum readouts (multi-scale
+or not, with the pooled rows entering the interaction graph's init_x), the mlp_concat pair scorer, BCE -- i.e. the
+LL-GNN ("lower_level_gnn") and BI-GNN ("lower_level_gnn_higher_level") models end to end -- with relu / identity /
+sigmoid / tanh activations.  GCN / GMN / multi-edge-type layers raise NotImplementedError in training mode.
 """
 
 import torch
 
 from . import ops
 
-__all__ = ["linear", "spmm_sum", "batch_norm_train", "segment_reduce_multi", "l2_normalize", "pair_gather",
+__all__ = ["linear", "gat_conv", "spmm_sum", "batch_norm_train", "segment_reduce_multi", "l2_normalize", "pair_gather",
            "training_active"]
 
 
@@ -65,6 +68,40 @@ class _Linear(torch.autograd.Function):
 
 def linear(x, weight, bias=None, act="identity"):
     return _Linear.apply(x, weight, bias, act)
+
+
+class _GatConv(torch.autograd.Function):
+    """y = act(GATConv(x) ), heads = 1 (model/layers.py:33,54): weight [in, out], att [1, 1, 2 out], bias [out]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, att, bias, csr, group, slope, act):
+        _check_act(act)
+        x, weight, att = x.detach(), weight.detach(), att.detach()
+        y, h, sc, stats = ops.gat_forward_saved(csr, x, weight, att, bias.detach(), group, slope, act)
+        ctx.csr, ctx.group, ctx.slope, ctx.act = csr, group, slope, act
+        ctx.save_for_backward(x, weight, att, h, sc, stats, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, att, h, sc, stats, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        g = dy if ctx.act == "identity" else ops.act_backward(dy, y, ctx.act)
+        dh, ds = ops.gat_backward(ctx.csr, h, sc, stats, g, att, ctx.group, ctx.slope)
+        dx = dw = datt = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear(dh, ops.transpose(weight.contiguous()), transform="f32")        # [n, out] @ [out, in]
+        if ctx.needs_input_grad[1]:
+            dw = ops.linear(ops.transpose(x.contiguous()), dh, transform="f32")             # [in, n] @ [n, out]
+        if ctx.needs_input_grad[2]:
+            datt = ops.linear(ds, h, transform="f32").reshape(att.shape)                    # [2, n] @ [n, out]
+        if ctx.needs_input_grad[3]:
+            db = ops.col_reduce(g, "sum")
+        return dx, dw, datt, db, None, None, None, None
+
+
+def gat_conv(x, weight, att, bias, csr, group="src", slope=0.2, act="identity"):
+    return _GatConv.apply(x, weight, att, bias, csr, group, slope, act)
 
 
 class _SpmmSum(torch.autograd.Function):

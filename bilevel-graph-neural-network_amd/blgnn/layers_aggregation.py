@@ -128,6 +128,22 @@ class NodeAggregation(NodeAggregationPairs):
     def forward(self, x, batch_data, model, pair_batch=False):
         if not FLAGS.higher_level_layers:
             return super().forward(x, batch_data, model, pair_batch)
+        if ag.training_active(self) and x.requires_grad:
+            # training (src/train.py:48-72 runs the sweep WITH gradients): the pooled rows enter init_x as an
+            # autograd value, so the loss reaches the molecular layers through the interaction-level layers
+            out = super().forward(x, batch_data, model, pair_batch)
+            graph = batch_data.interaction_combo_nxgraph
+            rows = batch_data.interaction_rows_of_batch_graphs()
+            rng = batch_data.interaction_row_range()
+            n_all = graph.number_of_nodes()
+            if rng is not None and rng[0] == 0 and rng[1] == n_all:
+                graph.init_x = out                                  # the sweep covers every drug, in gs_map order
+            else:
+                base = graph.init_x.detach() if isinstance(graph.init_x, torch.Tensor) and \
+                    graph.init_x.shape[1] == out.shape[1] else \
+                    torch.zeros((n_all, out.shape[1]), dtype=torch.float32, device=out.device)
+                graph.init_x = base.index_copy(0, rows.long(), out)     # row placement: data movement only
+            return out
         # layers_aggregation.py:68-74: init_x[gs_map[gid]] = out[ind]
         graph = batch_data.interaction_combo_nxgraph
         init_x = graph.init_x

@@ -681,3 +681,39 @@ def pair_scatter_add(dcat, col0, ids, dz):
     call("blgnn_pair_scatter_add", cp, ldc, int(col0), _vec(ids, "ids", torch.int64, False), ids.numel(), dz.shape[1],
          dzp, lddz, _stream())
     return dz
+
+
+def gat_forward_saved(csr, x, weight, att, bias, group="src", slope=0.2, act="identity"):
+    """GATConv forward that also returns what its backward needs: -> (y, h, sc [2, n], stats [2, n])."""
+    if group not in GAT_GROUP:
+        raise ValueError("softmax_group must be 'src' or 'dst'")
+    h, sc = gat_transform(x, weight, att)
+    n, d = h.shape
+    stats = torch.empty((2, n), dtype=torch.float32, device=h.device)
+    s = _stream()
+    hp, ldh = _mat(h, "h")
+    call("blgnn_gat_softmax_stats", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, sc[0].data_ptr(), sc[1].data_ptr(), n,
+         GAT_GROUP[group], float(slope), stats[0].data_ptr(), stats[1].data_ptr(), s)
+    y = torch.empty((n, d), dtype=torch.float32, device=h.device)
+    call("blgnn_gat_aggregate", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, hp, ldh, sc[0].data_ptr(),
+         sc[1].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), GAT_GROUP[group], float(slope), y.data_ptr(), d, n, d,
+         _vec(bias, "bias"), _act(act), None, None, None, 0, s)
+    return y, h, sc, stats
+
+
+def gat_backward(csr, h, sc, stats, dz, att, group="src", slope=0.2):
+    """-> (dh [n, d], ds [2, n]): gradient of the graph half of GATConv w.r.t. the transformed table and the two
+    attention halves (see include/blgnn.h: blgnn_gat_backward_*)."""
+    n, d = h.shape
+    hp, ldh = _mat(h, "h")
+    gp, ldg = _mat(dz, "dz")
+    ds = torch.zeros((2, n), dtype=torch.float32, device=h.device)
+    dh = torch.empty((n, d), dtype=torch.float32, device=h.device)
+    s = _stream()
+    call("blgnn_gat_backward_scores", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, hp, ldh, gp, ldg, sc[0].data_ptr(),
+         sc[1].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), n, d, GAT_GROUP[group], float(slope), ds[0].data_ptr(),
+         ds[1].data_ptr(), s)
+    call("blgnn_gat_backward_features", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, gp, ldg, sc[0].data_ptr(),
+         sc[1].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ds[0].data_ptr(), ds[1].data_ptr(),
+         _vec(att.reshape(-1).contiguous(), "att", optional=False), n, d, GAT_GROUP[group], float(slope), dh.data_ptr(), d, s)
+    return dh, ds

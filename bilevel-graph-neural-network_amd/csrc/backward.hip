@@ -164,7 +164,7 @@ __global__ void k_pair_scatter_add(const float *__restrict__ dcat, int64_t ldc, 
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)B * d) return;
     const int b = (int)(idx / d), c = (int)(idx % d);
-    atomicAdd(dz + ids[b] * lddz + c, dcat[(int64_t)b * ldc + col0 + c]);
+    unsafeAtomicAdd(dz + ids[b] * lddz + c, dcat[(int64_t)b * ldc + col0 + c]);
 }
 
 static unsigned grid_for(int64_t items, int threads) { return (unsigned)((items + threads - 1) / threads); }

@@ -443,6 +443,26 @@ int blgnn_l2_normalize_backward(const float *z, int64_t ldz, const float *dzn, i
 int blgnn_pair_scatter_add(const float *dcat, int64_t ldc, int32_t col0, const int64_t *ids,
                            int32_t B, int32_t d, float *dz, int64_t lddz, void *stream);
 
+/* Backward of the graph half of GATConv (model/layers.py:33,54), given dz = the gradient of
+ * z_i = sum_{j in N(i) u {i}} alpha_ij h_j and the forward's scores / softmax statistics.
+ * blgnn_gat_backward_scores: ds_dst[i], ds_src[j] = gradients of the two attention halves
+ *   (d alpha_ij = dz_i . h_j, softmax + leaky-relu backward per group); ds_* ZERO-INITIALISED by the
+ *   caller (the side opposite to the softmax group is accumulated with scalar float atomics).
+ * blgnn_gat_backward_features: dh_j = sum_i alpha_ij dz_i + ds_dst[j] att[0:d] + ds_src[j] att[d:2d].
+ * The caller finishes with blgnn_linear: datt = [ds_dst^T h, ds_src^T h], dW = x^T dh, dx = dh W^T.
+ * (rowptr, col) = the symmetric CSR the forward used. */
+int blgnn_gat_backward_scores(const int32_t *rowptr, const int32_t *col, int64_t nnz,
+                              const float *h, int64_t ldh, const float *dz, int64_t lddz,
+                              const float *s_dst, const float *s_src, const float *mx,
+                              const float *den, int32_t n, int32_t d, int32_t group, float slope,
+                              float *ds_dst, float *ds_src, void *stream);
+int blgnn_gat_backward_features(const int32_t *rowptr, const int32_t *col, int64_t nnz,
+                                const float *dz, int64_t lddz, const float *s_dst,
+                                const float *s_src, const float *mx, const float *den,
+                                const float *ds_dst, const float *ds_src, const float *att,
+                                int32_t n, int32_t d, int32_t group, float slope, float *dh,
+                                int64_t lddh, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

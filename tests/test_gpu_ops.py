@@ -601,6 +601,29 @@ def test_gmn_match(device, d, sizes):
     assert max_err(got, ref) < TOL
 
 
+def test_gmn_match_on_operands_beyond_4_gib(device):
+    """the output of the match is a column slice of the [Nn, 4D] f_node input; at configs[4] (657 k atoms, D = 512)
+    that buffer is 5.4 GB, so byte offsets from its base do not fit 32 bits -- pairs at both ends and in the middle
+    must still land in their own rows"""
+    sizes = [20, 21] * 14000 + [70, 90, 33, 2]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    n, d, ld = int(off[-1]), 64, 2048
+    assert n * ld * 4 > 4.6e9
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, d, generator=g)
+    seg = torch.as_tensor(off, dtype=torch.int32, device=device)
+    wide = torch.zeros((n, ld), device=device)
+    got = ops.gmn_match(seg, x.to(device), out=wide[:, 1024:1024 + d])
+    for first in (0, 6998, 13996, 13998, 14000):                 # pair index -> its two graphs
+        a, b = int(off[2 * first]), int(off[2 * first + 2])
+        ind = [(0, int(off[2 * first + 1]) - a), (int(off[2 * first + 1]) - a, b - a)]
+        ref = oracle.gmn_match(x[a:b].double(), ind)
+        assert max_err(got[a:b], ref) < TOL
+    assert float(wide[:, :1024].abs().max()) == 0.0 and float(wide[:, 1024 + d:].abs().max()) == 0.0
+    del wide
+    torch.cuda.empty_cache()
+
+
 def test_edge_relu_sum_matches_message(device):
     """restructured GMN message == reference formulation (layers_gmn.py:38-42)"""
     ei, _, n = molecule_graph(25, 9)

@@ -195,3 +195,74 @@ def test_llgnn_sgd_trajectory(device):
         got.append(float(loss.detach()))
     assert got[-1] < got[0]
     assert max(abs(a - b) for a, b in zip(got, ref)) < 1e-4, (got, ref)
+
+
+@pytest.mark.parametrize("group", ["src", "dst"])
+@pytest.mark.parametrize("n,deg,d,act", [(300, 6, 64, "relu"), (90, 40, 128, "identity"), (7, 2, 32, "tanh")])
+def test_gat_conv_backward(device, group, n, deg, d, act):
+    """GATConv backward (both softmax groupings; existing self loops, isolated nodes, rows of very different
+    length) against fp64 autograd on the oracle: dx, dW, datt, dbias"""
+    from test_gpu_ops import rand_graph
+    ei = rand_graph(n, deg, seed=n + deg, self_loops=True, isolated=2)
+    g = torch.Generator().manual_seed(d)
+    K = 48
+    x, w = torch.randn(n, K, generator=g), torch.randn(K, d, generator=g) / K ** 0.5
+    att, b = torch.randn(1, 1, 2 * d, generator=g) * 0.3, torch.randn(d, generator=g) * 0.1
+    if act == "relu":                      # keep pre-activations away from the kink (see test_linear_backward)
+        b = b + 3.0
+    dy = torch.randn(n, d, generator=g)
+    xr, wr, ar, br = _leaf(x), _leaf(w), _leaf(att), _leaf(b)
+    ref = oracle.ops.apply_act(oracle.ops.gat_conv(xr, ei, wr, ar, br, group), act)
+    ref.backward(dy.double())
+    xd, wd, ad, bd = _leaf(x, device), _leaf(w, device), _leaf(att, device), _leaf(b, device)
+    csr = ops.csr_from_edge_index(ei.to(device), n)
+    got = ag.gat_conv(xd, wd, ad, bd, csr, group=group, act=act)
+    got.backward(dy.to(device))
+    assert max_err(got, ref) < TOL
+    assert max_err(xd.grad, xr.grad) < TOL
+    assert max_err(wd.grad, wr.grad) < TOL
+    assert max_err(ad.grad, ar.grad) < TOL
+    assert max_err(bd.grad, br.grad) < TOL
+
+
+@pytest.mark.parametrize("lower", ["gin", "gat"])
+def test_bignn_training_step_gradients(device, lower):
+    """The bi-level model trained end to end as src/train.py:75-108,177-182 does it: the molecular sweep runs WITH
+    gradients, its pooled rows become the interaction graph's init_x, the interaction-level GAT layers and the pair
+    scorer produce the loss, and backward reaches every parameter of both levels.  Loss + all parameter gradients
+    against fp64 autograd on the oracle (train-mode BatchNorm on both sides)."""
+    from blgnn.forward import get_initial_embd, all_molecule_pairs
+    D = 64
+    ds = blgnn.make_synthetic(70, 500, seed=12, device=device)
+    flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type=lower, higher_level_gnn_type="gat",
+                             D_lower=D, D_higher=D, device=device)
+    model, data = build(flags, ds, seed=14)
+    specs = layer_specs(flags)
+    rng = np.random.default_rng(2)
+    pairs = ds.pair_gids[rng.choice(len(ds.pair_gids), size=40, replace=False)]
+    # ---- ours
+    model.train()
+    get_initial_embd(data, model)
+    ds.init_interaction_graph_embds(device)
+    assert ds.interaction_combo_nxgraph.init_x.requires_grad
+    bd = blgnn.BatchData(pairs, ds, sampled_gids=np.unique(pairs), is_train=True, rng=np.random.default_rng(3))
+    model.use_layers = 'higher_layers'
+    loss = model(bd)
+    loss.backward()
+    # ---- oracle: one layer list, the sweep's batch + the pair rows
+    lower_b = blgnn.BatchData(all_molecule_pairs(ds.gs_map.keys()), ds, is_train=False, ignore_pairs=True)
+    ids = torch.as_tensor(np.vectorize(ds.gs_map.get)(bd.batch_gids))
+    sd = _oracle_state(model)
+    of = dict(oracle_flags(flags, ds), train=True)
+    acts = oracle.run_layers(specs, sd, plain_batch(lower_b, ds, torch.float64, with_pairs=ids), of)
+    ref_loss = torch.nn.functional.binary_cross_entropy(acts[-1].view(-1), bd.true_labels().cpu().double())
+    ref_loss.backward()
+    assert max_err(loss, ref_loss) < TOL
+    checked = 0
+    for name, p in model.named_parameters():
+        if name not in sd or not name.startswith("layers."):
+            continue
+        assert p.grad is not None, name
+        assert max_err(p.grad, sd[name].grad) < TOL, name
+        checked += 1
+    assert checked >= 5 * (6 if lower == "gin" else 5) + 3 * 5 + 4
