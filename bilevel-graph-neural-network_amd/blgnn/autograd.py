@@ -24,7 +24,7 @@ import torch
 
 from . import ops
 
-__all__ = ["linear", "gat_conv", "spmm_sum", "batch_norm_train", "segment_reduce_multi", "l2_normalize", "pair_gather",
+__all__ = ["linear", "gat_conv", "multi_edge_gat", "spmm_sum", "batch_norm_train", "segment_reduce_multi", "l2_normalize", "pair_gather",
            "training_active"]
 
 
@@ -102,6 +102,55 @@ class _GatConv(torch.autograd.Function):
 
 def gat_conv(x, weight, att, bias, csr, group="src", slope=0.2, act="identity"):
     return _GatConv.apply(x, weight, att, bias, csr, group, slope, act)
+
+
+class _MultiEdgeGat(torch.autograd.Function):
+    """y = act( sum_k GATConv_k(x, edges_k) ): NodeModelAggrByEdge('gat') of the DrugCombo interaction level
+    (model/layers_meta.py:70,74-79).  params = (weight_0, att_0, bias_0, weight_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, x, csrs, group, slope, act, *params):
+        _check_act(act)
+        x = x.detach()
+        K = len(csrs)
+        saved, y = [], None
+        for k in range(K):
+            w, a, b = (p.detach() for p in params[3 * k:3 * k + 3])
+            # every edge type accumulates into the same buffer; the activation rides on the last pass
+            y, h, sc, stats = ops.gat_forward_saved(csrs[k], x, w, a, b, group, slope, act if k == K - 1 else "identity",
+                                                    out=y, accumulate=k > 0)
+            saved += [w, a, h, sc, stats]
+        ctx.csrs, ctx.group, ctx.slope, ctx.act, ctx.K = csrs, group, slope, act, K
+        ctx.save_for_backward(x, y, *saved)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors[:2]
+        saved = ctx.saved_tensors[2:]
+        dy = dy.contiguous()
+        g = dy if ctx.act == "identity" else ops.act_backward(dy, y, ctx.act)
+        xt = ops.transpose(x.contiguous())
+        db = ops.col_reduce(g, "sum")                                     # every edge type's bias sees the same g
+        grads, dhs, wts = [], [], []
+        for k in range(ctx.K):
+            w, a, h, sc, stats = saved[5 * k:5 * k + 5]
+            dh, ds = ops.gat_backward(ctx.csrs[k], h, sc, stats, g, a, ctx.group, ctx.slope)
+            grads += [ops.linear(xt, dh, transform="f32"), ops.linear(ds, h, transform="f32").reshape(a.shape), db]
+            dhs.append(dh)
+            wts.append(ops.transpose(w.contiguous()))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # sum_k dh_k W_k^T as ONE product over the concatenated inner dimension
+            dx = ops.linear(torch.cat(dhs, dim=1), torch.cat(wts, dim=0), transform="f32")
+        return (dx, None, None, None, None) + tuple(grads)
+
+
+def multi_edge_gat(x, convs, csrs, group="src", slope=0.2, act="identity"):
+    params = []
+    for c in convs:
+        params += [c.weight, c.att, c.bias]
+    return _MultiEdgeGat.apply(x, list(csrs), group, slope, act, *params)
 
 
 class _SpmmSum(torch.autograd.Function):

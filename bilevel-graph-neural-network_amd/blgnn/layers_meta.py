@@ -11,6 +11,7 @@ forces off -- they raise NotImplementedError here.
 import torch
 import torch.nn as nn
 
+from . import autograd as ag
 from . import ops
 from .config import FLAGS
 from .layers import GATConv, GCNConv
@@ -85,6 +86,14 @@ class MetaLayerWrapper(nn.Module):
         ops.require_device(ins, "ins")
         merge = batch_data.merge_higher_level['merge'] if self.higher_level \
             else batch_data.merge_data['merge']
+        if ag.training_active(self) and self.node_model.type == 'gat':
+            # training: sum over edge types of GATConv + act as one autograd node (blgnn/autograd.py)
+            graphs = list(batch_data.merge_higher_level['edges'].values())
+            return ag.multi_edge_gat(ins, list(self.node_model.GNNS)[:len(graphs)], [g.csr() for g in graphs],
+                                     group=getattr(FLAGS, "gat_softmax_group", "src"),
+                                     slope=self.node_model.GNNS[0].negative_slope, act=act_name(self.activation))
+        if ag.training_active(self):
+            raise NotImplementedError("blgnn: training covers the 'gat_multi_edge_aggr' node model")
         with torch.no_grad():
             return self.node_model(ins, merge.edge_index, merge.edge_attr, batch_data,
                                    final_act=act_name(self.activation))

@@ -683,8 +683,9 @@ def pair_scatter_add(dcat, col0, ids, dz):
     return dz
 
 
-def gat_forward_saved(csr, x, weight, att, bias, group="src", slope=0.2, act="identity"):
-    """GATConv forward that also returns what its backward needs: -> (y, h, sc [2, n], stats [2, n])."""
+def gat_forward_saved(csr, x, weight, att, bias, group="src", slope=0.2, act="identity", out=None, accumulate=False):
+    """GATConv forward that also returns what its backward needs: -> (y, h, sc [2, n], stats [2, n]).
+    ``accumulate``: add into ``out`` before the activation (sum over edge types)."""
     if group not in GAT_GROUP:
         raise ValueError("softmax_group must be 'src' or 'dst'")
     h, sc = gat_transform(x, weight, att)
@@ -694,10 +695,11 @@ def gat_forward_saved(csr, x, weight, att, bias, group="src", slope=0.2, act="id
     hp, ldh = _mat(h, "h")
     call("blgnn_gat_softmax_stats", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, sc[0].data_ptr(), sc[1].data_ptr(), n,
          GAT_GROUP[group], float(slope), stats[0].data_ptr(), stats[1].data_ptr(), s)
-    y = torch.empty((n, d), dtype=torch.float32, device=h.device)
+    y = _out(out, n, d, h)
+    yp, ldy = _mat(y, "out")
     call("blgnn_gat_aggregate", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, hp, ldh, sc[0].data_ptr(),
-         sc[1].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), GAT_GROUP[group], float(slope), y.data_ptr(), d, n, d,
-         _vec(bias, "bias"), _act(act), None, None, None, 0, s)
+         sc[1].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), GAT_GROUP[group], float(slope), yp, ldy, n, d,
+         _vec(bias, "bias"), _act(act), None, None, None, int(bool(accumulate)), s)
     return y, h, sc, stats
 
 

@@ -266,3 +266,45 @@ def test_bignn_training_step_gradients(device, lower):
         assert max_err(p.grad, sd[name].grad) < TOL, name
         checked += 1
     assert checked >= 5 * (6 if lower == "gin" else 5) + 3 * 5 + 4
+
+
+def test_drugcombo_bignn_training_gradients(device):
+    """DrugCombo variant of the bi-level model: the interaction level sums one GATConv per edge type
+    (NodeModelAggrByEdge('gat'), model/layers_meta.py:70,74-79) and the scorer emits one logit per label; gradients
+    of a fixed linear functional of the logits w.r.t. every parameter against the oracle"""
+    from blgnn.forward import get_initial_embd, all_molecule_pairs
+    ds = blgnn.make_synthetic(70, 500, seed=8, device=device, num_edge_types=2, name="drugcombo_syn")
+    flags = blgnn.make_flags("lower_level_gnn_higher_level", dataset="drugcombo", lower_level_gnn_type="gin",
+                             device=device)
+    model, data = build(flags, ds, seed=11, num_hyper_edge_feat=3)
+    specs = layer_specs(flags)
+    rng = np.random.default_rng(5)
+    pairs = ds.pair_gids[rng.choice(len(ds.pair_gids), size=32, replace=False)]
+    model.train()
+    get_initial_embd(data, model)
+    ds.init_interaction_graph_embds(device)
+    bd = blgnn.BatchData(pairs, ds, is_train=False)
+    model.use_layers = 'higher_layers'
+    model.acts = [bd.merge_data['merge'].x]
+    for layer in model._selected()[:-1]:
+        model.acts.append(layer(model.acts[-1], bd, model))
+    logits = model.acts[-1]
+    assert logits.shape == (32, 3) and logits.requires_grad
+    wgt = torch.randn(32, 3, generator=torch.Generator().manual_seed(0))
+    (logits * wgt.to(device)).sum().backward()
+
+    lower_b = blgnn.BatchData(all_molecule_pairs(ds.gs_map.keys()), ds, is_train=False, ignore_pairs=True)
+    ids = torch.as_tensor(np.vectorize(ds.gs_map.get)(bd.batch_gids))
+    sd = _oracle_state(model)
+    acts = oracle.run_layers(specs, sd, plain_batch(lower_b, ds, torch.float64, with_pairs=ids),
+                             dict(oracle_flags(flags, ds), train=True))
+    assert max_err(logits, acts[-1]) < TOL
+    (acts[-1] * wgt.double()).sum().backward()
+    checked = 0
+    for name, p in model.named_parameters():
+        if name not in sd or not name.startswith("layers.") or sd[name].grad is None:
+            continue
+        assert p.grad is not None, name
+        assert max_err(p.grad, sd[name].grad) < TOL, name
+        checked += 1
+    assert checked >= 30 + 3 * 3 * 2
