@@ -177,6 +177,13 @@ class NodeEmbedding(nn.Module):
                     plan = model._readout_plan = None
                 pool = plan.pool_for(self) if plan is not None else None
             fused_pool = False
+            wide = None
+            if self.type == 'gin' and out is None and not self.higher_level and not self.normalize \
+                    and 'gmn' in FLAGS.model:
+                # the GMNPropagator that follows reads this layer's output as the first D columns of its [n, 4D]
+                # f_node input (model/layers_gmn.py:44-46): produce it there instead of copying it later
+                wide = torch.empty((ins.shape[0], 4 * self.out_dim), dtype=torch.float32, device=ins.device)
+                out = wide[:, :self.out_dim]
             if self.type == 'gin':
                 lin1, lin2 = self.conv.nn[0], self.conv.nn[2]
                 w1 = self._cache.get("w1", lambda w: w.t().contiguous(), lin1.weight)
@@ -233,6 +240,8 @@ class NodeEmbedding(nn.Module):
                 if not fused_pool:          # this layer's kernel has no readout epilogue: one segment-reduce launch
                     ops.segment_reduce(plan.seg, x, plan.kind, out=pool[2])
                 plan.done.add(id(self))
+            if wide is not None:
+                x._blgnn_wide = wide
             model.store_layer_output(self, x)
             if self.normalize:
                 x = ops.l2_normalize_rows(x)

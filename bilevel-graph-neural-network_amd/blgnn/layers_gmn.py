@@ -99,8 +99,10 @@ class GMNPropagator(nn.Module):
             wpq, bpq, _, _ = self._message_weights()
             w1, b1, rw = self._node_weights()
             pq = ops.linear(x, wpq, bpq)                                  # [n, 4D] = [P | Q]
-            f_in = torch.empty((n, 4 * D), dtype=torch.float32, device=x.device)
-            f_in[:, :D].copy_(x)
+            f_in = getattr(x, "_blgnn_wide", None)               # the producing GIN layer already wrote x there
+            if f_in is None or tuple(f_in.shape) != (n, 4 * D) or f_in.data_ptr() != x.data_ptr():
+                f_in = torch.empty((n, 4 * D), dtype=torch.float32, device=x.device)
+                f_in[:, :D].copy_(x)
             ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:], out=f_in[:, D:3 * D])
             ops.gmn_match(merge.segments(), x, out=f_in[:, 3 * D:])
             act = act_name(self.f_node.activation)

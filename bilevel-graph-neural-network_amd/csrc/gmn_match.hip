@@ -567,7 +567,7 @@ extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const floa
     const int lds_bytes = (int)want;
     const int lds_floats = lds_bytes / 4;
     const int threads = lds_bytes > 80 * 1024 ? 512 : 256;
-    const int parts = skip_small >= 0 ? 8 : 1;
+    const int parts = skip_small >= 0 ? 32 : 1;   // the rare > 128-node pairs: 32 workgroups share the query rows of each
     const int64_t items = skip_small >= 0 ? (int64_t)(num_pairs + WAVE - 1) / WAVE * parts : (int64_t)num_pairs;
     const int blocks = (int)(items < 256 * 8 ? items : 256 * 8);
     const int ch = (d / 4 + WAVE - 1) / WAVE;
