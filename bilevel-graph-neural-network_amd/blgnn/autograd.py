@@ -14,17 +14,18 @@ every arithmetic step of both directions is a kernel behind the C ABI:
 
   GATConv            blgnn_gat_backward_scores / _features (+ blgnn_linear for datt, dW, dx)
 
-Scope: GIN and GAT NodeEmbedding layers on either level, the avg_pool / sum readouts (multi-scale
+Scope: GIN, GAT and GCN NodeEmbedding layers on either level, the avg_pool / sum readouts (multi-scale
 or not, with the pooled rows entering the interaction graph's init_x), the mlp_concat pair scorer, BCE -- i.e. the
 LL-GNN ("lower_level_gnn") and BI-GNN ("lower_level_gnn_higher_level") models end to end -- with relu / identity /
-sigmoid / tanh activations.  GCN / GMN / multi-edge-type layers raise NotImplementedError in training mode.
+sigmoid / tanh activations; GCN layers (without edge weights) and the multi-edge-type GAT interaction level of DrugCombo
+too.  GMN layers raise NotImplementedError in training mode.
 """
 
 import torch
 
 from . import ops
 
-__all__ = ["linear", "gat_conv", "multi_edge_gat", "spmm_sum", "batch_norm_train", "segment_reduce_multi", "l2_normalize", "pair_gather",
+__all__ = ["linear", "gat_conv", "gcn_conv", "multi_edge_gat", "spmm_sum", "batch_norm_train", "segment_reduce_multi", "l2_normalize", "pair_gather",
            "training_active"]
 
 
@@ -102,6 +103,35 @@ class _GatConv(torch.autograd.Function):
 
 def gat_conv(x, weight, att, bias, csr, group="src", slope=0.2, act="identity"):
     return _GatConv.apply(x, weight, att, bias, csr, group, slope, act)
+
+
+class _GcnConv(torch.autograd.Function):
+    """y = act(A_hat (x W) + b), GCNConv (model/layers.py:23,52) without edge weights; A_hat = D^-1/2 (A + I) D^-1/2 is
+    symmetric, so the gradient of the propagation is the propagation itself."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, csr, act):
+        _check_act(act)
+        x, weight = x.detach(), weight.detach()
+        y = ops.gcn_conv(csr, x, weight, bias.detach(), None, act=act)
+        ctx.csr, ctx.act = csr, act
+        ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        g = dy if ctx.act == "identity" else ops.act_backward(dy, y, ctx.act)
+        dh = ops.gcn_propagate(ctx.csr, g)
+        dx = ops.linear(dh, ops.transpose(weight.contiguous()), transform="f32") if ctx.needs_input_grad[0] else None
+        dw = ops.linear(ops.transpose(x.contiguous()), dh, transform="f32") if ctx.needs_input_grad[1] else None
+        db = ops.col_reduce(g, "sum") if ctx.needs_input_grad[2] else None
+        return dx, dw, db, None, None
+
+
+def gcn_conv(x, weight, bias, csr, act="identity"):
+    return _GcnConv.apply(x, weight, bias, csr, act)
 
 
 class _MultiEdgeGat(torch.autograd.Function):

@@ -251,10 +251,6 @@ class NodeEmbedding(nn.Module):
         """Train mode (src/train.py:177-182 runs backward through this layer): the same arithmetic as
         ``forward`` unfused -- GIN: aggregation, Linear+act, Linear+act; GAT: transform, softmax-weighted gather + act;
         then train-mode BatchNorm -- as autograd nodes whose both directions are libblgnn kernels (blgnn/autograd.py)."""
-        if self.type not in ('gin', 'gat'):
-            raise NotImplementedError(
-                "blgnn: training is implemented for GIN and GAT layers; '{}' layers run forward-only "
-                "(call model.eval() / torch.no_grad())".format(self.type))
         if out is not None:
             raise NotImplementedError("blgnn: train mode does not write into a caller-provided slice")
         csr = self._graph(batch_data).csr()
@@ -264,9 +260,13 @@ class NodeEmbedding(nn.Module):
             agg = ag.spmm_sum(ins, csr, 1.0 + float(self.conv.eps[0]))
             h = ag.linear(agg, lin1.weight, lin1.bias, act)
             x = ag.linear(h, lin2.weight, lin2.bias, act)           # conv, then the layer's act (layers.py:55)
-        else:
+        elif self.type == 'gat':
             x = ag.gat_conv(ins, self.conv.weight, self.conv.att, self.conv.bias, csr,
                             group=getattr(FLAGS, "gat_softmax_group", "src"), slope=self.conv.negative_slope, act=act)
+        else:
+            if getattr(batch_data.merge_data['merge'], "edge_attr", None) is not None:
+                raise NotImplementedError("blgnn: GCN layers train without edge weights (none of the shipped configs has any)")
+            x = ag.gcn_conv(ins, self.conv.weight, self.conv.bias, csr, act=act)
         if self.bn:
             x = ag.batch_norm_train(x, self.bn)
         model.store_layer_output(self, x)

@@ -482,6 +482,21 @@ def gcn_conv(csr, x, weight, bias, edge_weight=None, act="identity", act_param=N
     return y
 
 
+def gcn_propagate(csr, h, edge_weight=None):
+    """A_hat h with GCNConv's symmetric normalisation (no transform, no bias): the operator of the layer's forward
+    AND, because A_hat is symmetric on the undirected graphs of this path, of its backward."""
+    n, d = h.shape
+    hp, ldh = _mat(h, "h")
+    dis = torch.empty(n, dtype=torch.float32, device=h.device)
+    s = _stream()
+    wp = _vec(edge_weight, "edge_weight")
+    call("blgnn_gcn_deg_inv_sqrt", csr.rowptr.data_ptr(), csr.col.data_ptr(), wp, n, dis.data_ptr(), s)
+    y = torch.empty((n, d), dtype=torch.float32, device=h.device)
+    call("blgnn_gcn_aggregate", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, wp, dis.data_ptr(), hp, ldh,
+         y.data_ptr(), d, n, d, None, _act("identity"), None, None, None, 0, s)
+    return y
+
+
 def segment_reduce(seg, x, kind="mean", out=None, row_map=None):
     """scatter_mean / scatter_add over sorted segments; ``out`` may be a column
     slice of a wider buffer and ``row_map`` (int32[G]) redirects output rows."""

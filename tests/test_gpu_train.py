@@ -225,7 +225,25 @@ def test_gat_conv_backward(device, group, n, deg, d, act):
     assert max_err(bd.grad, br.grad) < TOL
 
 
-@pytest.mark.parametrize("lower", ["gin", "gat"])
+def test_gcn_conv_backward(device):
+    from test_gpu_ops import rand_graph
+    n, K, d = 400, 40, 64
+    ei = rand_graph(n, 5, seed=3, self_loops=True, isolated=3)
+    g = torch.Generator().manual_seed(2)
+    x, w, b = torch.randn(n, K, generator=g), torch.randn(K, d, generator=g) / K ** 0.5, torch.randn(d, generator=g)
+    dy = torch.randn(n, d, generator=g)
+    xr, wr, br = _leaf(x), _leaf(w), _leaf(b)
+    ref = torch.tanh(oracle.ops.gcn_conv(xr, ei, wr, br))
+    ref.backward(dy.double())
+    xd, wd, bd = _leaf(x, device), _leaf(w, device), _leaf(b, device)
+    got = ag.gcn_conv(xd, wd, bd, ops.csr_from_edge_index(ei.to(device), n), act="tanh")
+    got.backward(dy.to(device))
+    assert max_err(got, ref) < TOL
+    for a, r in ((xd, xr), (wd, wr), (bd, br)):
+        assert max_err(a.grad, r.grad) < TOL
+
+
+@pytest.mark.parametrize("lower", ["gin", "gat", "gcn"])
 def test_bignn_training_step_gradients(device, lower):
     """The bi-level model trained end to end as src/train.py:75-108,177-182 does it: the molecular sweep runs WITH
     gradients, its pooled rows become the interaction graph's init_x, the interaction-level GAT layers and the pair
@@ -265,7 +283,7 @@ def test_bignn_training_step_gradients(device, lower):
         assert p.grad is not None, name
         assert max_err(p.grad, sd[name].grad) < TOL, name
         checked += 1
-    assert checked >= 5 * (6 if lower == "gin" else 5) + 3 * 5 + 4
+    assert checked >= 5 * {"gin": 6, "gat": 5, "gcn": 4}[lower] + 3 * 5 + 4
 
 
 def test_drugcombo_bignn_training_gradients(device):
