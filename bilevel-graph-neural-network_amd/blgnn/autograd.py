@@ -26,7 +26,7 @@ import torch
 from . import ops
 
 __all__ = ["linear", "gat_conv", "gcn_conv", "multi_edge_gat", "spmm_sum", "batch_norm_train", "segment_reduce_multi", "l2_normalize", "pair_gather",
-           "training_active"]
+           "training_active", "set_batch_norm_sync"]
 
 
 def training_active(module):
@@ -200,29 +200,59 @@ def spmm_sum(x, csr, self_coef):
     return _SpmmSum.apply(x, csr, self_coef)
 
 
+_SYNC = {"reduce": None}
+
+
+def set_batch_norm_sync(reduce_fn):
+    """Data-parallel training (one process per GPU, each rank scoring its own pairs): train-mode BatchNorm must see the
+    statistics of the WHOLE batch.  ``reduce_fn(t)`` sums the float tensor ``t`` over the ranks in place and returns it
+    (``lambda t: (dist.all_reduce(t, group=g), t)[1]`` over RCCL); ``None`` switches synchronisation off.  What crosses
+    the wire per BatchNorm layer and direction is 2 N + 1 floats."""
+    _SYNC["reduce"] = reduce_fn
+
+
 class _BatchNormTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, stats_out):
         x = x.detach()
-        M = x.shape[0]
-        mean = ops.col_reduce(x, "sum", scale=1.0 / M)
-        var = ops.col_reduce(x, "sqdev", mean=mean, scale=1.0 / M)                # biased, two-pass
+        M, N = x.shape
+        red = _SYNC["reduce"]
+        if red is None:
+            count = float(M)
+            mean = ops.col_reduce(x, "sum", scale=1.0 / M)
+            var = ops.col_reduce(x, "sqdev", mean=mean, scale=1.0 / M)            # biased, two-pass
+        else:
+            # two-pass over the union of the ranks' rows: global sum -> mean, global centred squares -> variance
+            buf = torch.empty(N + 1, dtype=torch.float32, device=x.device)
+            ops.col_reduce(x, "sum", out=buf[:N])
+            buf[N] = float(M)
+            buf = red(buf)
+            count = float(buf[N])
+            mean = (buf[:N] / count).contiguous()
+            var = red(ops.col_reduce(x, "sqdev", mean=mean)) / count
         rstd = torch.rsqrt(var + eps)                                             # [N] vector glue
         y = ops.bn_apply(x, mean, rstd, None if gamma is None else gamma.detach(),
                          None if beta is None else beta.detach())
-        stats_out.extend((mean, var))
+        stats_out.extend((mean, var, count))
         ctx.save_for_backward(x, mean, rstd, gamma.detach() if gamma is not None else None)
         ctx.has_affine = gamma is not None
+        ctx.count = count
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, mean, rstd, gamma = ctx.saved_tensors
         dy = dy.contiguous()
-        M = x.shape[0]
-        dbeta = ops.col_reduce(dy, "sum")
-        dgamma = ops.col_reduce(dy, "dot_norm", b=x, mean=mean, rstd=rstd)        # sum dy * xhat
-        dx = ops.bn_backward(dy, x, mean, rstd, gamma, dgamma, dbeta) if ctx.needs_input_grad[0] else None
+        N = x.shape[1]
+        both = torch.empty((2, N), dtype=torch.float32, device=x.device)
+        dbeta = ops.col_reduce(dy, "sum", out=both[0])
+        dgamma = ops.col_reduce(dy, "dot_norm", b=x, mean=mean, rstd=rstd, out=both[1])     # sum dy * xhat
+        dx = None
+        if ctx.needs_input_grad[0]:
+            red = _SYNC["reduce"]
+            tot = both if red is None else red(both.clone())                     # dx needs the sums over ALL rows
+            dx = ops.bn_backward(dy, x, mean, rstd, gamma, tot[1], tot[0], count=ctx.count)
+        # the parameter gradients stay local sums (a data-parallel wrapper reduces parameter gradients itself)
         return dx, (dgamma if ctx.has_affine else None), (dbeta if ctx.has_affine else None), None, None
 
 
@@ -232,13 +262,12 @@ def batch_norm_train(x, bn):
     stats = []
     y = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps, stats)
     if bn.track_running_stats and bn.running_mean is not None:
-        mean, var = stats
-        M = x.shape[0]
+        mean, var, M = stats
         with torch.no_grad():
             bn.num_batches_tracked += 1
             mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
             bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
-            bn.running_var.mul_(1.0 - mom).add_(var * (M / max(M - 1, 1)), alpha=mom)
+            bn.running_var.mul_(1.0 - mom).add_(var * (M / max(M - 1.0, 1.0)), alpha=mom)
     return y
 
 

@@ -639,14 +639,14 @@ def bn_apply(x, mean, rstd, gamma=None, beta=None, out=None):
     return y
 
 
-def bn_backward(dy, x, mean, rstd, gamma, dgamma, dbeta, out=None):
+def bn_backward(dy, x, mean, rstd, gamma, dgamma, dbeta, out=None, count=None):
     dyp, lddy = _mat(dy, "dy")
     xp, ldx = _mat(x, "x")
     dx = _out(out, x.shape[0], x.shape[1], x)
     dxp, lddx = _mat(dx, "out")
     call("blgnn_bn_backward", dyp, lddy, xp, ldx, _vec(mean, "mean", optional=False), _vec(rstd, "rstd", optional=False),
          _vec(gamma, "gamma"), _vec(dgamma, "dgamma", optional=False), _vec(dbeta, "dbeta", optional=False),
-         x.shape[0], x.shape[1], dxp, lddx, _stream())
+         x.shape[0], x.shape[1], int(round(count)) if count is not None else x.shape[0], dxp, lddx, _stream())
     return dx
 
 

@@ -74,12 +74,12 @@ __global__ void k_bn_apply(const float *__restrict__ x, int64_t ldx, const float
 __global__ void k_bn_backward(const float *__restrict__ dy, int64_t lddy, const float *__restrict__ x, int64_t ldx,
                               const float *__restrict__ mean, const float *__restrict__ rstd,
                               const float *__restrict__ gamma, const float *__restrict__ dgamma,
-                              const float *__restrict__ dbeta, int M, int N, float *__restrict__ dx, int64_t lddx) {
+                              const float *__restrict__ dbeta, int M, int N, float inv_m, float *__restrict__ dx,
+                              int64_t lddx) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)M * N) return;
     const int r = (int)(idx / N), c = (int)(idx % N);
     const float xh = (x[(int64_t)r * ldx + c] - mean[c]) * rstd[c];
-    const float inv_m = 1.f / (float)M;
     dx[(int64_t)r * lddx + c] = (gamma ? gamma[c] : 1.f) * rstd[c] *
                                 (dy[(int64_t)r * lddy + c] - dbeta[c] * inv_m - xh * dgamma[c] * inv_m);
 }
@@ -210,12 +210,12 @@ extern "C" int blgnn_bn_apply(const float *x, int64_t ldx, const float *mean, co
 
 extern "C" int blgnn_bn_backward(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *mean,
                                  const float *rstd, const float *gamma, const float *dgamma, const float *dbeta,
-                                 int32_t M, int32_t N, float *dx, int64_t lddx, void *stream) {
-    BLGNN_CHECK_ARG(M >= 0 && N > 0 && lddy >= N && ldx >= N && lddx >= N, "bn_backward: bad sizes");
+                                 int32_t M, int32_t N, int64_t count, float *dx, int64_t lddx, void *stream) {
+    BLGNN_CHECK_ARG(M >= 0 && N > 0 && lddy >= N && ldx >= N && lddx >= N && count >= M, "bn_backward: bad sizes");
     if (M == 0) return BLGNN_OK;
     BLGNN_CHECK_ARG(dy && x && mean && rstd && dgamma && dbeta && dx, "bn_backward: null pointer");
     hipLaunchKernelGGL(k_bn_backward, dim3(grid_for((int64_t)M * N, 256)), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx,
-                       mean, rstd, gamma, dgamma, dbeta, M, N, dx, lddx);
+                       mean, rstd, gamma, dgamma, dbeta, M, N, 1.f / (float)count, dx, lddx);
     return launch_status("bn_backward");
 }
 

@@ -409,12 +409,14 @@ int blgnn_bn_apply(const float *x, int64_t ldx, const float *mean, const float *
                    const float *gamma, const float *beta, int32_t M, int32_t N, float *y,
                    int64_t ldy, void *stream);
 
-/* Train-mode BatchNorm1d backward given dgamma = sum dy * xhat and dbeta = sum dy:
- *   dx = gamma * rstd * (dy - dbeta / M - xhat * dgamma / M),  xhat = (x - mean) * rstd. */
+/* Train-mode BatchNorm1d backward given dgamma = sum dy * xhat and dbeta = sum dy over the `count` rows the
+ * statistics were taken over (count = M on one GPU; the global row count when the sums were all-reduced
+ * across data-parallel ranks):
+ *   dx = gamma * rstd * (dy - dbeta / count - xhat * dgamma / count),  xhat = (x - mean) * rstd. */
 int blgnn_bn_backward(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *mean,
                       const float *rstd, const float *gamma, const float *dgamma,
-                      const float *dbeta, int32_t M, int32_t N, float *dx, int64_t lddx,
-                      void *stream);
+                      const float *dbeta, int32_t M, int32_t N, int64_t count, float *dx,
+                      int64_t lddx, void *stream);
 
 /* dx = dy * act'(.) evaluated from the activation's OUTPUT y (relu / prelu with positive slopes /
  * sigmoid / tanh / identity); dx may alias dy. */

@@ -178,12 +178,40 @@ def require_device(t, name="tensor"):
     return None
 
 
+def col_reduce(a, mode="sum", b=None, mean=None, rstd=None, scale=1.0, out=None):
+    if mode == "sum":
+        v = a.sum(0)
+    elif mode == "dot":
+        v = (a * b).sum(0)
+    elif mode == "sqdev":
+        v = ((a - mean) ** 2).sum(0)
+    else:
+        v = (a * (b - mean) * rstd).sum(0)
+    return _put(out, v * scale)
+
+
+def bn_apply(x, mean, rstd, gamma=None, beta=None, out=None):
+    y = (x - mean) * rstd
+    if gamma is not None:
+        y = y * gamma
+    if beta is not None:
+        y = y + beta
+    return _put(out, y)
+
+
+def bn_backward(dy, x, mean, rstd, gamma, dgamma, dbeta, out=None, count=None):
+    m = float(count if count is not None else x.shape[0])
+    xh = (x - mean) * rstd
+    g = gamma if gamma is not None else 1.0
+    return _put(out, g * rstd * (dy - dbeta / m - xh * dgamma / m))
+
+
 NAMES = ["csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear", "linear_writes_amax", "row_absmax",
          "gin_layer_h3_codes_supported",
          "gin_layer",
          "gin_layer_supported", "gin_layer_x6_supported", "gat_conv", "gcn_conv",
          "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum", "row_degree", "pair_gather_normalize", "link_pred_head",
-         "l2_normalize_rows", "scatter_rows", "require_device"]
+         "l2_normalize_rows", "scatter_rows", "require_device", "col_reduce", "bn_apply", "bn_backward"]
 
 
 def install(monkeypatch):

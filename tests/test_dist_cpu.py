@@ -138,3 +138,63 @@ def test_bench_gpus_n_starts_n_ranks_itself():
     # a launcher environment that disagrees with --gpus is an error, not a silent 1-GPU line
     r = _run_bench({"BLGNN_BENCH_RENDEZVOUS_ONLY": "1", "WORLD_SIZE": "1", "RANK": "0"}, "--gpus", "2")
     assert r.returncode != 0
+
+
+def _sync_bn_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    for p in (conftest.ROOT, os.path.join(conftest.ROOT, "bilevel-graph-neural-network_amd"),
+              os.path.join(conftest.ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fake_backend
+        from blgnn import autograd as ag
+        from blgnn import ops as real_ops
+        for n in fake_backend.NAMES:
+            setattr(real_ops, n, getattr(fake_backend, n))
+        g = torch.Generator().manual_seed(0)
+        M, N = 101, 16                                        # unequal shares: 60 + 41 rows
+        x_all, dy_all = torch.randn(M, N, generator=g) * 2 + 1, torch.randn(M, N, generator=g)
+        lo, hi = (0, 60) if rank == 0 else (60, M)
+        bn = torch.nn.BatchNorm1d(N)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(N, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(N, generator=g))
+        ag.set_batch_norm_sync(lambda t: (dist.all_reduce(t), t)[1])
+        x = x_all[lo:hi].clone().requires_grad_(True)
+        y = ag.batch_norm_train(x, bn)
+        y.backward(dy_all[lo:hi])
+        ag.set_batch_norm_sync(None)
+        # parameter gradients are local sums: a data-parallel wrapper adds them up
+        gw, gb = bn.weight.grad.clone(), bn.bias.grad.clone()
+        dist.all_reduce(gw); dist.all_reduce(gb)
+        ret[rank] = {"y": y.detach(), "dx": x.grad, "gw": gw, "gb": gb, "rm": bn.running_mean.clone(),
+                     "rv": bn.running_var.clone(), "lo": lo, "hi": hi, "x": x_all, "dy": dy_all,
+                     "w": bn.weight.detach().clone(), "b": bn.bias.detach().clone()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_train_mode_batch_norm_equals_the_whole_batch():
+    """train-mode BatchNorm under data parallelism (src/train.py:177-182 on N GPUs): statistics and the two
+    backward sums are all-reduced, so every rank normalises with the whole batch's mean / variance"""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_sync_bn_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    r0 = ret[0]
+    ref_bn = torch.nn.BatchNorm1d(r0["x"].shape[1])
+    with torch.no_grad():
+        ref_bn.weight.copy_(r0["w"]); ref_bn.bias.copy_(r0["b"])
+    x = r0["x"].clone().requires_grad_(True)
+    y = ref_bn(x)
+    y.backward(r0["dy"])
+    for r in (ret[0], ret[1]):
+        assert torch.allclose(r["y"], y[r["lo"]:r["hi"]].detach(), atol=1e-5)
+        assert torch.allclose(r["dx"], x.grad[r["lo"]:r["hi"]], atol=1e-5)
+        assert torch.allclose(r["gw"], ref_bn.weight.grad, atol=1e-4)
+        assert torch.allclose(r["gb"], ref_bn.bias.grad, atol=1e-4)
+        assert torch.allclose(r["rm"], ref_bn.running_mean, atol=1e-6)
+        assert torch.allclose(r["rv"], ref_bn.running_var, atol=1e-5)

@@ -326,3 +326,58 @@ def test_drugcombo_bignn_training_gradients(device):
         assert max_err(p.grad, sd[name].grad) < TOL, name
         checked += 1
     assert checked >= 30 + 3 * 3 * 2
+
+
+def test_train_mode_batch_norm_synchronised_over_two_shards(device):
+    """data-parallel train-mode BatchNorm (autograd.set_batch_norm_sync): each of two shards of one batch is processed
+    with a reduce hook that adds what the OTHER shard would have contributed to the all-reduce (computed with the same
+    kernels on the other shard's rows); every shard must normalise with the whole batch's statistics and produce the
+    whole batch's input gradient"""
+    g = torch.Generator().manual_seed(4)
+    M, N = 3001, 128
+    x_all, dy_all = torch.randn(M, N, generator=g) * 1.5 + 0.3, torch.randn(M, N, generator=g)
+    ref_bn = torch.nn.BatchNorm1d(N).double()
+    with torch.no_grad():
+        ref_bn.weight.copy_(torch.rand(N, generator=g) + 0.5); ref_bn.bias.copy_(torch.randn(N, generator=g))
+    xr = _leaf(x_all)
+    ref = ref_bn(xr)
+    ref.backward(dy_all.double())
+    bounds = [(0, 1800), (1800, M)]
+
+    def other_rank(x_o, dy_o):
+        st = {"k": 0}
+
+        def reduce(t):
+            k = st["k"]; st["k"] += 1
+            if k == 0:                                     # [sum_x | rows]
+                t[:N] += ops.col_reduce(x_o, "sum"); t[N] += float(x_o.shape[0])
+                st["count"] = float(t[N]); st["mean"] = (t[:N] / t[N]).contiguous()
+            elif k == 1:                                   # centred squares
+                t += ops.col_reduce(x_o, "sqdev", mean=st["mean"])
+                st["rstd"] = torch.rsqrt(t / st["count"] + ref_bn.eps)
+            else:                                          # [dbeta ; dgamma]
+                t[0] += ops.col_reduce(dy_o, "sum")
+                t[1] += ops.col_reduce(dy_o, "dot_norm", b=x_o, mean=st["mean"], rstd=st["rstd"])
+            return t
+        return reduce
+
+    grads = []
+    for r, (lo, hi) in enumerate(bounds):
+        olo, ohi = bounds[1 - r]
+        bn = torch.nn.BatchNorm1d(N).to(device)
+        with torch.no_grad():
+            bn.weight.copy_(ref_bn.weight.float()); bn.bias.copy_(ref_bn.bias.float())
+        ag.set_batch_norm_sync(other_rank(x_all[olo:ohi].to(device), dy_all[olo:ohi].to(device)))
+        try:
+            x = _leaf(x_all[lo:hi], device)
+            y = ag.batch_norm_train(x, bn)
+            y.backward(dy_all[lo:hi].to(device))
+        finally:
+            ag.set_batch_norm_sync(None)
+        assert max_err(y, ref[lo:hi]) < TOL
+        assert max_err(x.grad, xr.grad[lo:hi]) < TOL
+        assert max_err(bn.running_var, ref_bn.running_var) < TOL
+        assert max_err(bn.running_mean, ref_bn.running_mean) < TOL
+        grads.append((bn.weight.grad, bn.bias.grad))
+    assert max_err(grads[0][0] + grads[1][0], ref_bn.weight.grad) < TOL      # local sums: the wrapper adds them up
+    assert max_err(grads[0][1] + grads[1][1], ref_bn.bias.grad) < TOL
