@@ -70,7 +70,7 @@ SIGNATURES = {
     "blgnn_stream_create_cu_mask": [_p, _i32, _p],
     "blgnn_stream_destroy": [_p],
     "blgnn_col_reduce": [_p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, _f32, _p, _p, _p],
-    "blgnn_bn_apply": [_p, _i64, _p, _p, _p, _p, _i32, _i32, _p, _i64, _p],
+    "blgnn_bn_apply": [_p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p],
     "blgnn_bn_backward": [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i32, _i32, _i64, _p, _i64, _p],
     "blgnn_act_backward": [_p, _i64, _p, _i64, _i32, _p, _i32, _i32, _p, _i64, _p],
     "blgnn_transpose": [_p, _i64, _i32, _i32, _p, _i64, _p],
@@ -78,6 +78,8 @@ SIGNATURES = {
     "blgnn_l2_normalize_backward": [_p, _i64, _p, _i64, _i32, _i32, _f32, _p, _i64, _p],
     "blgnn_pair_scatter_add": [_p, _i64, _i32, _p, _i32, _i32, _p, _i64, _p],
     "blgnn_gat_backward_scores": [_p, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _p, _p, _p],
+    "blgnn_edge_relu_sum_backward": [_p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p, _i64, _p],
+    "blgnn_gmn_match_backward": [_p, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i32, _i64, _p],
     "blgnn_gat_backward_features": [_p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _p, _i64, _p],
 }
 LIBRARY_SYMBOLS = ["blgnn_version", "blgnn_last_error", "blgnn_device_count", "blgnn_packed_weight_x6_elems",

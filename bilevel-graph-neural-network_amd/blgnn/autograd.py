@@ -18,14 +18,14 @@ Scope: GIN, GAT and GCN NodeEmbedding layers on either level
 or not, with the pooled rows entering the interaction graph's init_x), the mlp_concat pair scorer, BCE -- i.e. the
 LL-GNN ("lower_level_gnn") and BI-GNN ("lower_level_gnn_higher_level") models end to end -- with relu / identity /
 sigmoid / tanh activations; GCN layers (without edge weights) and the multi-edge-type GAT interaction level of DrugCombo
-too.  GMN layers raise NotImplementedError in training mode.
+too, and the GMN propagator (message, cross-graph attention, f_node MLP with train-mode BatchNorm).
 """
 
 import torch
 
 from . import ops
 
-__all__ = ["linear", "gat_conv", "gcn_conv", "multi_edge_gat", "spmm_sum", "batch_norm_train", "segment_reduce_multi", "l2_normalize", "pair_gather",
+__all__ = ["linear", "gat_conv", "gcn_conv", "multi_edge_gat", "edge_relu_sum", "gmn_match", "spmm_sum", "batch_norm_train", "segment_reduce_multi", "l2_normalize", "pair_gather",
            "training_active", "set_batch_norm_sync"]
 
 
@@ -213,7 +213,8 @@ def set_batch_norm_sync(reduce_fn):
 
 class _BatchNormTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, stats_out):
+    def forward(ctx, x, gamma, beta, eps, stats_out, act="identity"):
+        _check_act(act)
         x = x.detach()
         M, N = x.shape
         red = _SYNC["reduce"]
@@ -232,17 +233,21 @@ class _BatchNormTrain(torch.autograd.Function):
             var = red(ops.col_reduce(x, "sqdev", mean=mean)) / count
         rstd = torch.rsqrt(var + eps)                                             # [N] vector glue
         y = ops.bn_apply(x, mean, rstd, None if gamma is None else gamma.detach(),
-                         None if beta is None else beta.detach())
+                         None if beta is None else beta.detach(), act=act)
         stats_out.extend((mean, var, count))
-        ctx.save_for_backward(x, mean, rstd, gamma.detach() if gamma is not None else None)
+        ctx.save_for_backward(x, mean, rstd, gamma.detach() if gamma is not None else None,
+                              y if act != "identity" else None)
         ctx.has_affine = gamma is not None
         ctx.count = count
+        ctx.act = act
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, mean, rstd, gamma = ctx.saved_tensors
+        x, mean, rstd, gamma, y = ctx.saved_tensors
         dy = dy.contiguous()
+        if ctx.act != "identity":
+            dy = ops.act_backward(dy, y, ctx.act)
         N = x.shape[1]
         both = torch.empty((2, N), dtype=torch.float32, device=x.device)
         dbeta = ops.col_reduce(dy, "sum", out=both[0])
@@ -253,14 +258,15 @@ class _BatchNormTrain(torch.autograd.Function):
             tot = both if red is None else red(both.clone())                     # dx needs the sums over ALL rows
             dx = ops.bn_backward(dy, x, mean, rstd, gamma, tot[1], tot[0], count=ctx.count)
         # the parameter gradients stay local sums (a data-parallel wrapper reduces parameter gradients itself)
-        return dx, (dgamma if ctx.has_affine else None), (dbeta if ctx.has_affine else None), None, None
+        return dx, (dgamma if ctx.has_affine else None), (dbeta if ctx.has_affine else None), None, None, None
 
 
-def batch_norm_train(x, bn):
+def batch_norm_train(x, bn, act="identity"):
     """torch.nn.BatchNorm1d in train mode (model/layers.py:39-40,56-57), including the running-statistics
-    update (momentum form, unbiased variance) torch performs as a side effect."""
+    update (momentum form, unbiased variance) torch performs as a side effect.  ``act``: the activation that
+    follows the BatchNorm inside an MLP (model/layers_util.py:51-54), fused into the same kernels."""
     stats = []
-    y = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps, stats)
+    y = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps, stats, act)
     if bn.track_running_stats and bn.running_mean is not None:
         mean, var, M = stats
         with torch.no_grad():
@@ -269,6 +275,47 @@ def batch_norm_train(x, bn):
             bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
             bn.running_var.mul_(1.0 - mom).add_(var * (M / max(M - 1.0, 1.0)), alpha=mom)
     return y
+
+
+class _EdgeReluSum(torch.autograd.Function):
+    """S_i = sum_{j in N(i)} relu(P_i + Q_j): the restructured GMN message (model/layers_gmn.py:38-42)."""
+
+    @staticmethod
+    def forward(ctx, p, q, csr):
+        p, q = p.detach().contiguous(), q.detach().contiguous()
+        ctx.csr = csr
+        ctx.save_for_backward(p, q)
+        return ops.edge_relu_sum(csr, p, q)
+
+    @staticmethod
+    def backward(ctx, ds):
+        p, q = ctx.saved_tensors
+        dp, dq = ops.edge_relu_sum_backward(ctx.csr, p, q, ds.contiguous())
+        return dp, dq, None
+
+
+def edge_relu_sum(p, q, csr):
+    return _EdgeReluSum.apply(p, q, csr)
+
+
+class _GmnMatch(torch.autograd.Function):
+    """u = x - cross-graph attention of the partner graph (model/layers_gmn.py:55-84), pairs = consecutive graphs."""
+
+    @staticmethod
+    def forward(ctx, x, seg):
+        x = x.detach().contiguous()
+        ctx.seg = seg
+        ctx.save_for_backward(x)
+        return ops.gmn_match(seg, x)
+
+    @staticmethod
+    def backward(ctx, du):
+        (x,) = ctx.saved_tensors
+        return ops.gmn_match_backward(ctx.seg, x, du.contiguous()), None
+
+
+def gmn_match(x, seg):
+    return _GmnMatch.apply(x, seg)
 
 
 class _SegmentReduceMulti(torch.autograd.Function):

@@ -95,6 +95,8 @@ class GMNPropagator(nn.Module):
         else:
             csr = merge.csr()
         n, D = x.shape
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(x, csr, merge, model)
         with torch.no_grad():
             wpq, bpq, _, _ = self._message_weights()
             w1, b1, rw = self._node_weights()
@@ -111,6 +113,24 @@ class GMNPropagator(nn.Module):
                 hid_amax = torch.zeros(n, dtype=torch.float32, device=x.device)
             hid = ops.linear(f_in, w1, b1, act=act, rowvec=ops.row_degree(csr), rowvec_w=rw, amax_out=hid_amax)
             out = ops.linear(hid, self.f_node.weight_kn(1), self.f_node.layers[1].bias, row_amax=hid_amax)
+        model.store_layer_output(self, out)
+        return out
+
+    def _forward_train(self, x, csr, merge, model):
+        """Train mode (src/train.py:177-182): the same restructured message, the cross-graph attention and the f_node
+        MLP with train-mode BatchNorm as autograd nodes on libblgnn kernels (blgnn/autograd.py).  The weight-only
+        products of the eval path (W2 folded into f_node) are not used: every Linear keeps its own gradient."""
+        from . import autograd as ag
+        D = self.input_dim
+        lin1, lin2 = self.f_messasge.layers[0], self.f_messasge.layers[1]
+        p = ag.linear(x, lin1.weight[:, :D], lin1.bias)                       # [x_i | x_j] @ W1^T split by halves
+        q = ag.linear(x, lin1.weight[:, D:], None)
+        s = ag.edge_relu_sum(p, q, csr)                                        # sum_e relu(P_i + Q_j)
+        # m_sum = S @ W2^T + deg * b2 as ONE product on [S | deg] and [W2 | b2] (concatenation: data movement)
+        deg = ops.row_degree(csr).view(-1, 1)
+        m_sum = ag.linear(torch.cat([s, deg], dim=1), torch.cat([lin2.weight, lin2.bias.view(-1, 1)], dim=1), None)
+        u = ag.gmn_match(x, merge.segments())
+        out = self.f_node(torch.cat([x, m_sum, u], dim=1))
         model.store_layer_output(self, out)
         return out
 

@@ -147,10 +147,15 @@ class MLP(nn.Module):
         if self.training and torch.is_grad_enabled() and x.requires_grad:
             # train mode: Linear(+act) autograd nodes on libblgnn kernels (blgnn/autograd.py)
             from . import autograd as ag
-            if self.bn or first_rowvec is not None or out is not None:
-                raise NotImplementedError("blgnn: training covers MLPs without BatchNorm (the pair scorer's)")
+            if first_rowvec is not None or out is not None:
+                raise NotImplementedError("blgnn: train mode takes neither a rank-1 term nor a destination slice")
             for i, lin in enumerate(self.layers):
-                x = ag.linear(x, lin.weight, lin.bias, final_act if i == last else act)
+                if i == last:
+                    x = ag.linear(x, lin.weight, lin.bias, final_act)
+                elif self.bn:                                    # Linear -> BN -> act (layers_util.py:51-54)
+                    x = ag.batch_norm_train(ag.linear(x, lin.weight, lin.bias, "identity"), self.bn[i], act=act)
+                else:
+                    x = ag.linear(x, lin.weight, lin.bias, act)
             return x
         amax = row_amax
         for i, lin in enumerate(self.layers):

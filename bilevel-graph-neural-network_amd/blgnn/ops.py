@@ -630,12 +630,12 @@ def col_reduce(a, mode="sum", b=None, mean=None, rstd=None, scale=1.0, out=None)
     return out
 
 
-def bn_apply(x, mean, rstd, gamma=None, beta=None, out=None):
+def bn_apply(x, mean, rstd, gamma=None, beta=None, out=None, act="identity"):
     xp, ldx = _mat(x, "x")
     y = _out(out, x.shape[0], x.shape[1], x)
     yp, ldy = _mat(y, "out")
     call("blgnn_bn_apply", xp, ldx, _vec(mean, "mean", optional=False), _vec(rstd, "rstd", optional=False),
-         _vec(gamma, "gamma"), _vec(beta, "beta"), x.shape[0], x.shape[1], yp, ldy, _stream())
+         _vec(gamma, "gamma"), _vec(beta, "beta"), x.shape[0], x.shape[1], _act(act), yp, ldy, _stream())
     return y
 
 
@@ -734,3 +734,35 @@ def gat_backward(csr, h, sc, stats, dz, att, group="src", slope=0.2):
          sc[1].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ds[0].data_ptr(), ds[1].data_ptr(),
          _vec(att.reshape(-1).contiguous(), "att", optional=False), n, d, GAT_GROUP[group], float(slope), dh.data_ptr(), d, s)
     return dh, ds
+
+
+def edge_relu_sum_backward(csr, p, q, ds):
+    """-> (dp, dq) of ``edge_relu_sum`` on a symmetric CSR."""
+    pp, ldp = _mat(p, "p")
+    qp, ldq = _mat(q, "q")
+    gp, ldg = _mat(ds, "ds")
+    n, d = p.shape
+    dp = torch.empty((n, d), dtype=torch.float32, device=p.device)
+    dq = torch.empty((n, d), dtype=torch.float32, device=p.device)
+    call("blgnn_edge_relu_sum_backward", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, pp, ldp, qp, ldq, gp, ldg,
+         n, d, dp.data_ptr(), d, dq.data_ptr(), d, _stream())
+    return dp, dq
+
+
+def gmn_match_backward(seg, x, du):
+    """dx of ``gmn_match`` (pairs = consecutive graphs of ``seg``)."""
+    xp, ldx = _mat(x, "x")
+    gp, ldg = _mat(du, "du")
+    n, d = x.shape
+    P = (seg.numel() - 1) // 2
+    sizes = (seg[1:] - seg[:-1]).to(torch.int64)                      # device-side index arithmetic (plumbing)
+    cells = sizes[0::2] * sizes[1::2]
+    cell_off = torch.zeros(P + 1, dtype=torch.int64, device=x.device)
+    torch.cumsum(cells, 0, out=cell_off[1:])
+    total_cells = int(cell_off[-1])
+    cell_scratch = torch.empty(max(4 * total_cells, 1), dtype=torch.float32, device=x.device)
+    row_scratch = torch.empty(max(3 * n, 1), dtype=torch.float32, device=x.device)
+    dx = torch.empty((n, d), dtype=torch.float32, device=x.device)
+    call("blgnn_gmn_match_backward", _vec(seg, "seg", torch.int32, False), P, xp, ldx, gp, ldg, cell_off.data_ptr(),
+         total_cells, cell_scratch.data_ptr(), row_scratch.data_ptr(), dx.data_ptr(), d, d, n, _stream())
+    return dx

@@ -63,11 +63,12 @@ __global__ void k_col_final(const float *__restrict__ partial, int chunks, int N
 // y = (x - mean) * rstd * gamma + beta
 __global__ void k_bn_apply(const float *__restrict__ x, int64_t ldx, const float *__restrict__ mean,
                            const float *__restrict__ rstd, const float *__restrict__ gamma,
-                           const float *__restrict__ beta, int M, int N, float *__restrict__ y, int64_t ldy) {
+                           const float *__restrict__ beta, int M, int N, int act, float *__restrict__ y, int64_t ldy) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)M * N) return;
     const int r = (int)(idx / N), c = (int)(idx % N);
-    y[(int64_t)r * ldy + c] = fmaf((x[(int64_t)r * ldx + c] - mean[c]) * rstd[c], gamma ? gamma[c] : 1.f, beta ? beta[c] : 0.f);
+    y[(int64_t)r * ldy + c] = apply_act(fmaf((x[(int64_t)r * ldx + c] - mean[c]) * rstd[c], gamma ? gamma[c] : 1.f,
+                                             beta ? beta[c] : 0.f), act, 0.f);
 }
 
 // dx = gamma * rstd * (dy - dbeta / M - xhat * dgamma / M),  xhat = (x - mean) * rstd
@@ -199,12 +200,14 @@ extern "C" int blgnn_col_reduce(const float *a, int64_t lda, const float *b, int
 }
 
 extern "C" int blgnn_bn_apply(const float *x, int64_t ldx, const float *mean, const float *rstd, const float *gamma,
-                              const float *beta, int32_t M, int32_t N, float *y, int64_t ldy, void *stream) {
+                              const float *beta, int32_t M, int32_t N, int32_t act, float *y, int64_t ldy,
+                              void *stream) {
     BLGNN_CHECK_ARG(M >= 0 && N > 0 && ldx >= N && ldy >= N, "bn_apply: bad sizes");
+    BLGNN_CHECK_ARG(act >= 0 && act <= BLGNN_ACT_TANH && act != BLGNN_ACT_PRELU, "bn_apply: bad activation id");
     if (M == 0) return BLGNN_OK;
     BLGNN_CHECK_ARG(x && mean && rstd && y, "bn_apply: null pointer");
     hipLaunchKernelGGL(k_bn_apply, dim3(grid_for((int64_t)M * N, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, mean, rstd,
-                       gamma, beta, M, N, y, ldy);
+                       gamma, beta, M, N, act, y, ldy);
     return launch_status("bn_apply");
 }
 

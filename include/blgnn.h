@@ -404,10 +404,11 @@ int blgnn_col_reduce(const float *a, int64_t lda, const float *b, int64_t ldb, c
                      const float *rstd, int32_t M, int32_t N, int32_t mode, float scale,
                      float *scratch, float *out, void *stream);
 
-/* Train-mode BatchNorm1d forward: y = (x - mean) * rstd * gamma + beta (gamma / beta nullable). */
+/* Train-mode BatchNorm1d forward: y = act((x - mean) * rstd * gamma + beta) (gamma / beta nullable;
+ * act = the activation that follows the BatchNorm in MLP: model/layers_util.py:51-54). */
 int blgnn_bn_apply(const float *x, int64_t ldx, const float *mean, const float *rstd,
-                   const float *gamma, const float *beta, int32_t M, int32_t N, float *y,
-                   int64_t ldy, void *stream);
+                   const float *gamma, const float *beta, int32_t M, int32_t N, int32_t act,
+                   float *y, int64_t ldy, void *stream);
 
 /* Train-mode BatchNorm1d backward given dgamma = sum dy * xhat and dbeta = sum dy over the `count` rows the
  * statistics were taken over (count = M on one GPU; the global row count when the sums were all-reduced
@@ -464,6 +465,22 @@ int blgnn_gat_backward_features(const int32_t *rowptr, const int32_t *col, int64
                                 const float *ds_dst, const float *ds_src, const float *att,
                                 int32_t n, int32_t d, int32_t group, float slope, float *dh,
                                 int64_t lddh, void *stream);
+
+/* Backward of blgnn_edge_relu_sum on a SYMMETRIC CSR (model/layers_gmn.py:38-42):
+ *   dp[i] = sum_{j in N(i)} [p_i + q_j > 0] ds[i],   dq[i] = sum_{j in N(i)} [p_j + q_i > 0] ds[j]. */
+int blgnn_edge_relu_sum_backward(const int32_t *rowptr, const int32_t *col, int64_t nnz,
+                                 const float *p, int64_t ldp, const float *q, int64_t ldq,
+                                 const float *ds, int64_t ldds, int32_t n, int32_t d, float *dp,
+                                 int64_t lddp, float *dq, int64_t lddq, void *stream);
+
+/* Backward of blgnn_gmn_match (model/layers_gmn.py:55-84): dx from du, per pair of graphs, any size.
+ * cell_off: device int64[num_pairs + 1], first cell of every pair's n1 x n2 matrices (prefix sum of
+ * n1 * n2); cell_scratch: 4 * total_cells floats; row_scratch: 3 * total_rows floats (total_rows =
+ * seg[2 * num_pairs]).  dx must not alias x / du. */
+int blgnn_gmn_match_backward(const int32_t *seg, int32_t num_pairs, const float *x, int64_t ldx,
+                             const float *du, int64_t lddu, const int64_t *cell_off,
+                             int64_t total_cells, float *cell_scratch, float *row_scratch,
+                             float *dx, int64_t lddx, int32_t d, int64_t total_rows, void *stream);
 
 #ifdef __cplusplus
 }

@@ -136,7 +136,7 @@ def run_layers(specs, sd, plain, flags, first=0, x0=None):
             out = ops.gmn_propagator(
                 x, plain["edge_index"], plain["ind_list"],
                 _mlp_params(sd, p + ".f_messasge")[0],
-                *_mlp_params(sd, p + ".f_node"))
+                *_mlp_params(sd, p + ".f_node"), train=bool(flags.get("train")))
         elif name in ("NodeAggregation", "NodeAggregationPairs"):
             out = _aggregation(x, info, sd, p, plain, flags, acts)
         elif name == "LoadInteractionLayer":

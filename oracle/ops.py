@@ -138,15 +138,15 @@ def l2_normalize(x, eps=1e-12):
     return x / x.norm(2, dim=1, keepdim=True).clamp_min(eps)
 
 
-def mlp(x, linears, act="relu", bns=None):
+def mlp(x, linears, act="relu", bns=None, train=False):
     """model/layers_util.py:44-57.  ``linears`` = [(W[out,in], b[out]), ...];
     every layer but the last is Linear -> [BN] -> act; the last is Linear only.
-    ``bns`` = [(weight, bias, mean, var), ...] for the hidden layers or None."""
+    ``bns`` = [(weight, bias, mean, var), ...] for the hidden layers or None; ``train``: batch statistics."""
     for i, (w, b) in enumerate(linears):
         x = x @ w.t() + b
         if i != len(linears) - 1:
             if bns:
-                x = batch_norm_eval(x, *bns[i])
+                x = batch_norm_train(x, bns[i][0], bns[i][1]) if train else batch_norm_eval(x, *bns[i])
             x = apply_act(x, act)
     return x
 
@@ -254,11 +254,11 @@ def gmn_message_sum(x, edge_index, msg_linears):
     return scatter_add(m, row, x.shape[0])
 
 
-def gmn_propagator(x, edge_index, ind_list, msg_linears, node_linears, node_bns):
+def gmn_propagator(x, edge_index, ind_list, msg_linears, node_linears, node_bns, train=False):
     """model/layers_gmn.py:34-53 with f_node='MLP' (bn=True)."""
     m_sum = gmn_message_sum(x, edge_index, msg_linears)
     u_sum = gmn_match(x, ind_list)
-    return mlp(torch.cat((x, m_sum, u_sum), dim=1), node_linears, "relu", node_bns)
+    return mlp(torch.cat((x, m_sum, u_sum), dim=1), node_linears, "relu", node_bns, train=train)
 
 
 # --------------------------------------------------------------------------

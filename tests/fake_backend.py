@@ -190,13 +190,13 @@ def col_reduce(a, mode="sum", b=None, mean=None, rstd=None, scale=1.0, out=None)
     return _put(out, v * scale)
 
 
-def bn_apply(x, mean, rstd, gamma=None, beta=None, out=None):
+def bn_apply(x, mean, rstd, gamma=None, beta=None, out=None, act="identity"):
     y = (x - mean) * rstd
     if gamma is not None:
         y = y * gamma
     if beta is not None:
         y = y + beta
-    return _put(out, y)
+    return _put(out, oracle.apply_act(y, act, None))
 
 
 def bn_backward(dy, x, mean, rstd, gamma, dgamma, dbeta, out=None, count=None):

@@ -381,3 +381,68 @@ def test_train_mode_batch_norm_synchronised_over_two_shards(device):
         grads.append((bn.weight.grad, bn.bias.grad))
     assert max_err(grads[0][0] + grads[1][0], ref_bn.weight.grad) < TOL      # local sums: the wrapper adds them up
     assert max_err(grads[0][1] + grads[1][1], ref_bn.bias.grad) < TOL
+
+
+def test_edge_relu_sum_and_gmn_match_backward(device):
+    """the two GMN-specific operators: gradients of sum_e relu(P_i + Q_j) and of the cross-graph attention (pairs with
+    small, tile-edge, > 64- and > 128-node graphs, an empty graph) against fp64 autograd on the oracle"""
+    from test_gpu_ops import molecule_graph
+    ei, _, n = molecule_graph(30, 5)
+    g = torch.Generator().manual_seed(8)
+    d = 48
+    p, q = torch.randn(n, d, generator=g) + 0.2, torch.randn(n, d, generator=g)
+    ds_ = torch.randn(n, d, generator=g)
+    pr, qr = _leaf(p), _leaf(q)
+    ref = oracle.ops.scatter_add(torch.relu(pr[ei[0]] + qr[ei[1]]), ei[0], n)
+    ref.backward(ds_.double())
+    pd, qd = _leaf(p, device), _leaf(q, device)
+    got = ag.edge_relu_sum(pd, qd, ops.csr_from_edge_index(ei.to(device), n))
+    got.backward(ds_.to(device))
+    assert max_err(got, ref) < TOL
+    assert max_err(pd.grad, pr.grad) < TOL and max_err(qd.grad, qr.grad) < TOL
+
+    sizes = [5, 7, 33, 31, 64, 65, 130, 20, 0, 9, 1, 1]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    ind = [(int(off[i]), int(off[i + 1])) for i in range(len(sizes))]
+    D = 64
+    x, du = torch.randn(int(off[-1]), D, generator=g), torch.randn(int(off[-1]), D, generator=g)
+    xr = _leaf(x)
+    ref = oracle.ops.gmn_match(xr, ind)
+    ref.backward(du.double())
+    xd = _leaf(x, device)
+    got = ag.gmn_match(xd, torch.as_tensor(off, dtype=torch.int32, device=device))
+    got.backward(du.to(device))
+    assert max_err(got, ref) < TOL
+    assert max_err(xd.grad, xr.grad) < TOL
+
+
+def test_mhcaddi_gmn_training_step_gradients(device):
+    """the GMN model (lower_level_gmn: GIN + GMNPropagator layers, pair mode) under loss.backward(): loss and every
+    parameter gradient against fp64 autograd on the oracle, train-mode BatchNorm in the layers and inside f_node"""
+    ds = blgnn.make_synthetic(40, 200, seed=6, device=device)
+    flags = blgnn.make_flags("lower_level_gmn", lower_level_gnn_type="gin", D_lower=64, device=device)
+    model, data = build(flags, ds, seed=9)
+    specs = layer_specs(flags)
+    rng = np.random.default_rng(1)
+    pairs = ds.pair_gids[rng.choice(len(ds.pair_gids), size=16, replace=False)]
+    bd = blgnn.BatchData(pairs, ds, sampled_gids=np.unique(pairs), is_train=True, unique_graphs=False,
+                         rng=np.random.default_rng(2))
+    B = len(bd.batch_gids)
+    ids = torch.arange(2 * B).reshape(-1, 2)
+    sd = _oracle_state(model)
+    of = dict(oracle_flags(flags, ds), train=True)
+    acts = oracle.run_layers(specs, sd, plain_batch(bd, ds, torch.float64, with_pairs=ids), of)
+    ref_loss = torch.nn.functional.binary_cross_entropy(acts[-1].view(-1), bd.true_labels().cpu().double())
+    ref_loss.backward()
+    model.train()
+    loss = model(bd)
+    loss.backward()
+    assert max_err(loss, ref_loss) < TOL
+    checked = 0
+    for name, p in model.named_parameters():
+        if name not in sd or not name.startswith("layers.") or sd[name].grad is None:
+            continue
+        assert p.grad is not None, name
+        assert max_err(p.grad, sd[name].grad) < TOL, name
+        checked += 1
+    assert checked >= 3 * 6 + 3 * 10
