@@ -89,6 +89,36 @@ def test_gat_two_nodes_by_hand():
                                  e01 / (e01 + e00) * 1 + e11 / (e11 + e10) * 3 + 0.25], abs=1e-12)
 
 
+def test_gat_three_node_path_asymmetric_attention_by_hand():
+    """3-node path 0-1-2, d = 2, att[:d] != att[d:]: every alpha written out edge by edge from the 1.1.x
+    ``message()`` formula quoted in SURVEY section 8c(5) -- alpha_e = leaky_relu(h_i . att[:d] + h_j . att[d:]) for the
+    edge j -> i, softmax over the edges sharing edge_index[0] ('src': the edges LEAVING a node) or edge_index[1]
+    ('dst': the edges ENTERING it).  The two groupings give different numbers here, so the test pins which is which."""
+    h = [[1.0, 2.0], [0.5, -1.0], [-2.0, 0.25]]
+    a_dst, a_src = [0.7, -0.3], [-0.4, 0.9]
+    edges = [(1, 0), (0, 1), (2, 1), (1, 2), (0, 0), (1, 1), (2, 2)]          # (source j, target i), self loops appended
+    lr = lambda v: v if v > 0 else 0.2 * v
+    dot = lambda u, v: sum(p * q for p, q in zip(u, v))
+    score = {(j, i): lr(dot(h[i], a_dst) + dot(h[j], a_src)) for j, i in edges}
+    exp = {}
+    for group in ("src", "dst"):
+        key = (lambda j, i: j) if group == "src" else (lambda j, i: i)
+        den = {}
+        for (j, i), sc in score.items():
+            den[key(j, i)] = den.get(key(j, i), 0.0) + math.exp(sc)
+        out = [[0.1, -0.2] for _ in range(3)]                                # bias
+        for (j, i), sc in score.items():
+            al = math.exp(sc) / den[key(j, i)]
+            out[i] = [o + al * v for o, v in zip(out[i], h[j])]
+        exp[group] = out
+    assert max(abs(a - b) for ra, rb in zip(exp["src"], exp["dst"]) for a, b in zip(ra, rb)) > 0.05
+    W, att, b = torch.eye(2, dtype=torch.float64), T(*(a_dst + a_src)).view(1, 1, 4), T(0.1, -0.2).view(-1)
+    for group in ("src", "dst"):
+        got = oracle.gat_conv(T(*h), P3, W, att, b, group).tolist()
+        for g_row, e_row in zip(got, exp[group]):
+            assert g_row == pytest.approx(e_row, abs=1e-12)
+
+
 def test_scatter_mean_clamps_empty_segments():
     x = T([2.0], [4.0], [9.0])
     idx = torch.tensor([0, 0, 2])
