@@ -94,6 +94,8 @@ def parse():
                          "the interaction-level stream gets the rest.  0 = ordinary streams; -1 = the measured "
                          "optimum (20 at 1 GPU, 16 at 2, none from 4 GPUs on / for the large configs)")
     ap.add_argument("--readout-with-upper", action="store_true")
+    ap.add_argument("--gmn-streams", type=int, default=1,
+                    help="GMN configs: consecutive steps (independent pair batches) alternate over this many streams")
     ap.add_argument("--no-fuse-readout", action="store_true",
                     help="bi-level configs: a separate segment-reduce launch instead of the readout fused into the "
                          "GIN layers' epilogues")
@@ -610,9 +612,16 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
     try:
         last = [None]
 
+        n_streams = max(int(getattr(args, "gmn_streams", 1)), 1)
+        lanes = [torch.cuda.Stream(device=device) for _ in range(n_streams)] if n_streams > 1 else None
+
         def one(i):
-            last[0] = forward(i)
-        for i in range(warmup):
+            if lanes is None:
+                last[0] = forward(i)
+            else:
+                with torch.cuda.stream(lanes[i % n_streams]):
+                    last[0] = forward(i)
+        for i in range(max(warmup, 2 * n_streams)):
             one(i)
         run_block, counter = block_runner(D, one, torch.cuda.synchronize, steps)
         counter[0] = warmup

@@ -55,7 +55,8 @@ class GMNPropagator(nn.Module):
 
     @classmethod
     def _side_stream(cls, device):
-        key = str(device)
+        """one side stream per launch stream (two forwards pipelined on two streams keep separate side streams)"""
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
         if key not in cls._streams:
             cls._streams[key] = torch.cuda.Stream(device=device)
         return cls._streams[key]
