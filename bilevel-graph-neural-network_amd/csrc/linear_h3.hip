@@ -29,6 +29,7 @@
 // does not fit): 25 % fewer operand bytes per MFMA, but the feeder's 32 KB of X per step stays the same and
 // becomes the bound -- 3.71 ms vs 3.70 ms on 462 k x 1024 x 1024 (1.30 vs 1.44 ms at K = 256), with 1.7x the
 // rounding error (7.8e-7 vs 4.6e-7 of the largest entry).
+#include <cstdlib>
 #include "linear_common.hpp"
 #include "h3_common.hpp"
 
@@ -331,9 +332,38 @@ static int launch_linear_h3(const LinearH3Args &P, hipStream_t s) {
 
 }  // namespace blgnn
 
+#include "linear_h3w.hpp"
+
+namespace blgnn {
+
+template <int ACT>
+static int launch_linear_h3w(const LinearH3Args &P, hipStream_t s) {
+    static bool declared = false;
+    if (!declared) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_h3w<ACT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS) != hipSuccess)
+            return fail(BLGNN_ERR_LAUNCH, "linear_h3: cannot raise the dynamic LDS limit to %d bytes", W_LDS);
+        declared = true;
+    }
+    const int64_t blocks = (int64_t)((P.base.M + W_BM - 1) / W_BM) * ((P.base.N + W_BN - 1) / W_BN);
+    hipLaunchKernelGGL(k_linear_h3w<ACT>, dim3((unsigned)blocks), dim3(512), W_LDS, s, P);
+    return launch_status("linear_h3");
+}
+
+// Which tile shape a weight of N columns is packed for -- and therefore which kernel multiplies by it.  A pure
+// function of N (and of BLGNN_H3_WIDE=0, which pins the 128 x 128 kernel for A/B measurements), so the packer and
+// the product agree without a tag in the image.
+static bool h3_wide(int N) {
+    static const bool allowed = [] { const char *e = getenv("BLGNN_H3_WIDE"); return !(e && e[0] == '0'); }();
+    return allowed && N % W_BN == 0;
+}
+
+}  // namespace blgnn
+
 using namespace blgnn;
 
 extern "C" int64_t blgnn_packed_weight_h3g_elems(int32_t K, int32_t N) {
+    if (h3_wide(N)) return HHDR + ((int64_t)N / W_BN) * (((int64_t)K + WBK - 1) / WBK) * (W_WTILE / 2);
     const int64_t KS = ((int64_t)K + HBK - 1) / HBK, NB = ((int64_t)N + 127) / 128;
     return HHDR + NB * KS * (H3_WTILE / 2);               // fp16 elements
 }
@@ -349,6 +379,13 @@ extern "C" int blgnn_pack_weight_h3g(const float *w, int64_t ldw, int32_t K, int
     const int64_t total = (int64_t)K * N;
     hipLaunchKernelGGL(k_absmax_g, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)), dim3(256), 0, s,
                        w, ldw, K, N, amax);
+    if (h3_wide(N)) {
+        const int KSW = (K + WBK - 1) / WBK;
+        const int64_t wwords = (int64_t)(N / W_BN) * KSW * W_BN * 4;
+        hipLaunchKernelGGL(k_pack_h3w, dim3((unsigned)((wwords + 255) / 256)), dim3(256), 0, s, w, ldw, K, N, KSW, amax,
+                           reinterpret_cast<_Float16 *>(out));
+        return launch_status("pack_weight_h3g");
+    }
     const int64_t words = (int64_t)NB * KS * 128 * 8;
     hipLaunchKernelGGL(k_pack_h3g, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, w, ldw, K, N, KS, amax,
                        reinterpret_cast<_Float16 *>(out));
@@ -385,8 +422,18 @@ extern "C" int blgnn_linear_h3(const float *x, int64_t ldx, const float *row_ama
     A.vec_a = 1; A.vec_b = 0; A.amax_out = y_row_amax;
     P.wp = reinterpret_cast<const _Float16 *>(w_packed);
     P.row_amax = row_amax;
-    P.KS = (K + HBK - 1) / HBK;
     hipStream_t s = (hipStream_t)stream;
+    if (h3_wide(N)) {
+        P.KS = (K + WBK - 1) / WBK;
+        switch (act) {
+            case BLGNN_ACT_RELU:    return launch_linear_h3w<BLGNN_ACT_RELU>(P, s);
+            case BLGNN_ACT_PRELU:   return launch_linear_h3w<BLGNN_ACT_PRELU>(P, s);
+            case BLGNN_ACT_SIGMOID: return launch_linear_h3w<BLGNN_ACT_SIGMOID>(P, s);
+            case BLGNN_ACT_TANH:    return launch_linear_h3w<BLGNN_ACT_TANH>(P, s);
+            default:                return launch_linear_h3w<BLGNN_ACT_IDENTITY>(P, s);
+        }
+    }
+    P.KS = (K + HBK - 1) / HBK;
     switch (act) {
         case BLGNN_ACT_RELU:    return launch_linear_h3<BLGNN_ACT_RELU>(P, s);
         case BLGNN_ACT_PRELU:   return launch_linear_h3<BLGNN_ACT_PRELU>(P, s);
