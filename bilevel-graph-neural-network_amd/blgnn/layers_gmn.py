@@ -126,7 +126,8 @@ class GMNPropagator(nn.Module):
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     ops.gmn_match(seg, x, out=f_in[:, 3 * D:])
-            pq = ops.linear(x, wpq, bpq)                                  # [n, 4D] = [P | Q]
+            h3 = ops.linear_writes_amax(x, wpq)                           # the f16x3 GEMM takes row magnitudes
+            pq = ops.linear(x, wpq, bpq, row_amax=ops.row_absmax(x) if h3 else None)      # [n, 4D] = [P | Q]
             ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:], out=f_in[:, D:3 * D])
             if side is not None:
                 cur.wait_stream(side)
@@ -136,7 +137,8 @@ class GMNPropagator(nn.Module):
             hid_amax = None
             if ops.linear_writes_amax(f_in, w1):
                 hid_amax = torch.zeros(n, dtype=torch.float32, device=x.device)
-            hid = ops.linear(f_in, w1, b1, act=act, rowvec=ops.row_degree(csr), rowvec_w=rw, amax_out=hid_amax)
+            hid = ops.linear(f_in, w1, b1, act=act, rowvec=ops.row_degree(csr), rowvec_w=rw, amax_out=hid_amax,
+                             row_amax=ops.row_absmax(f_in) if hid_amax is not None else None)
             out = ops.linear(hid, self.f_node.weight_kn(1), self.f_node.layers[1].bias, row_amax=hid_amax)
         model.store_layer_output(self, out)
         return out
