@@ -258,7 +258,10 @@ def test_gin_layer_f16x3_range(device, xs, ws):
 
 @pytest.mark.parametrize("transform", ["f16x3", "bf16x6"])
 @pytest.mark.parametrize("M,N,K", [(32768, 128, 128), (33001, 64, 52), (32800, 100, 36), (11000, 300, 260),
-                                   (32769, 1, 8), (16500, 256, 1024), (9000, 1024, 512)])
+                                   (32769, 1, 8), (16500, 256, 1024), (9000, 1024, 512),
+                                   # N % 256 == 0: the 128 x 256 / K-step-32 variant of the f16x3 kernel -- ragged M, K not a
+                                   # multiple of the step, a single K step, one and several column tiles
+                                   (33001, 256, 36), (8200, 512, 100), (40000, 768, 32), (20000, 256, 260)])
 def test_linear_split_shapes(device, M, N, K, transform):
     """split GEMMs on the 16-bit matrix cores (large-M path of ops.linear: fp16 two-piece / bf16 three-piece)
     == fp64 oracle at the fp32 bar"""
