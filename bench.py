@@ -93,6 +93,10 @@ def parse():
                     help="bi-level configs: compute units per XCD (of 32) reserved for the molecular sweep's stream; "
                          "the interaction-level stream gets the rest.  0 = ordinary streams; -1 = the measured "
                          "optimum (20 at 1 GPU, 16 at 2, none from 4 GPUs on / for the large configs)")
+    ap.add_argument("--train", action="store_true",
+                    help="instead of the forward metric: time TRAINING steps of the bi-level model at the DrugBank shape "
+                         "(molecular sweep with gradients -> interaction level -> BCE -> backward -> SGD; "
+                         "src/train.py:75-108,177-182) and print one JSON line for them")
     ap.add_argument("--readout-with-upper", action="store_true")
     ap.add_argument("--gmn-streams", type=int, default=1,
                     help="GMN configs: consecutive steps (independent pair batches) alternate over this many streams")
@@ -762,6 +766,95 @@ def rendezvous_only(args):
     return 0
 
 
+def run_train(args, D, transform, steps, warmup):
+    """Training step of the BI-GNN model (lower GIN x5 + upper GAT x3, d=128) at the DrugBank shape, one GPU:
+    what src/train.py does per iteration -- the molecular sweep over ALL drugs with gradients, a sampled pair batch
+    with one negative per positive, BCE, backward through both levels, optimizer step.  Every forward and backward
+    step is a libblgnn kernel behind autograd nodes (blgnn/autograd.py); the optimizer is torch's."""
+    import numpy as np
+    import torch
+    import blgnn
+    import oracle
+    import helpers
+    from blgnn.batch import BatchData
+    from blgnn.forward import all_molecule_pairs, get_initial_embd
+    cfg = CONFIGS[1]
+    device = D.device
+    d, batch = cfg["d"], 2048                                # 2 048 positives + 2 048 sampled negatives = 4 096 scored pairs
+    ds = blgnn.make_synthetic(cfg["drugs"], cfg["pairs"], shape=cfg["shape"], seed=SEED + 7, device=device)
+    flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin", higher_level_gnn_type="gat",
+                             D_lower=d, D_higher=d, device=device, batch_size=batch, feature_transform=transform)
+    blgnn.set_flags(flags)
+    torch.manual_seed(SEED)
+    data = blgnn.TrainData(ds, device=device)
+    ds.init_interaction_graph_feats(flags.init_embds, device, flags.d_init)
+    model = blgnn.Model(data).to(device)
+    model.train()
+    params = [p for k, p in model.named_parameters() if k.startswith("layers.")]
+    opt = torch.optim.SGD(params, lr=0.01, momentum=0.9)
+    rng = np.random.default_rng(SEED)
+    lower_cache = []
+    losses = []
+
+    def step(_i):
+        pos = ds.pair_gids[rng.choice(len(ds.pair_gids), size=batch, replace=False)]
+        opt.zero_grad(set_to_none=True)
+        get_initial_embd(data, model, cached_batches=lower_cache)          # sweep WITH gradients -> init_x
+        ds.init_interaction_graph_embds(device)
+        bd = BatchData(pos, ds, sampled_gids=np.unique(pos), is_train=True, rng=rng)
+        model.use_layers = 'higher_layers'
+        loss = model(bd)
+        loss.backward()
+        opt.step()
+        losses.append(loss.detach())
+        return len(bd.batch_gids)
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    scored = 0
+    for i in range(steps):
+        scored += step(i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    first, last = float(torch.stack(losses[:3]).mean()), float(torch.stack(losses[-3:]).mean())
+    out = {"metric": "DDI edge-pairs/sec (bi-level TRAINING step: forward + backward + SGD)", "value": scored / el,
+           "unit": "pairs/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * el / steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_OF[transform],
+           "data": "synthetic",
+           "config": {"workload": "TRAINING, DrugBank-shape DDI, lower GIN x5 + upper GAT x3, d=128: sweep over all %d "
+                                  "drugs with gradients + %d positive and as many sampled negative pairs per step"
+                                  % (cfg["drugs"], batch),
+                      "atoms": int(lower_cache[0].merge_data['merge'].x.shape[0]), "optimizer": "SGD(momentum 0.9)",
+                      "loss_first3_mean": first, "loss_last3_mean": last}}
+    if not args.no_cpu_baseline:
+        # the oracle with torch autograd on the host cores: same model, same sizes, bounded number of steps
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        specs = helpers.layer_specs(flags)
+        of = dict(helpers.oracle_flags(flags, ds), train=True)
+        pnames = {k for k, _ in model.named_parameters()}
+        sd = {k: (v.clone().requires_grad_(k in pnames) if v.is_floating_point() else v)
+              for k, v in helpers.state_dict_cpu(model).items()}
+        lower_b = BatchData(all_molecule_pairs(ds.gs_map.keys()), ds, is_train=False, ignore_pairs=True)
+        n, c0 = 0, time.perf_counter()
+        while True:
+            pos = ds.pair_gids[rng.choice(len(ds.pair_gids), size=batch, replace=False)]
+            bd = BatchData(pos, ds, sampled_gids=np.unique(pos), is_train=True, rng=rng)
+            ids = torch.as_tensor(np.vectorize(ds.gs_map.get)(bd.batch_gids))
+            acts = oracle.run_layers(specs, sd, helpers.plain_batch(lower_b, ds, with_pairs=ids), of)
+            loss = torch.nn.functional.binary_cross_entropy(acts[-1].view(-1), bd.true_labels().cpu().float())
+            loss.backward()
+            n += 1
+            if time.perf_counter() - c0 > args.cpu_seconds or n >= 50:
+                break
+        ce = time.perf_counter() - c0
+        out["cpu_baseline"] = {"value": n * 2 * batch / ce, "unit": "pairs/s", "cores": cores, "kind": "port",
+                               "sample": "%d training steps (forward + torch autograd backward, no optimizer step) of "
+                                         "the same model and sizes on the oracle, %.1f s" % (n, ce)}
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -771,6 +864,12 @@ def main():
     import torch                                            # noqa: F401  (first GPU-touching import of a rank)
     D = Dist(args)
     transform = "f32" if args.exact_f32 else args.transform
+    if args.train:
+        if D.world != 1:
+            raise SystemExit("bench.py --train measures one GPU")
+        print(json.dumps(run_train(args, D, transform, args.steps, args.warmup)), flush=True)
+        D.close()
+        return 0
     cfg = CONFIGS[args.config]
     runner = run_bilevel if cfg["kind"] == "bilevel" else run_gmn
     res = runner(args.config, args, D, transform, args.steps, args.warmup, args.min_seconds)

@@ -70,6 +70,7 @@ SIGNATURES = {
     "blgnn_stream_create_cu_mask": [_p, _i32, _p],
     "blgnn_stream_destroy": [_p],
     "blgnn_col_reduce": [_p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, _f32, _p, _p, _p],
+    "blgnn_grad_weight": [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p],
     "blgnn_bn_apply": [_p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p],
     "blgnn_bn_backward": [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i32, _i32, _i64, _p, _i64, _p],
     "blgnn_act_backward": [_p, _i64, _p, _i64, _i32, _p, _i32, _i32, _p, _i64, _p],
@@ -84,7 +85,7 @@ SIGNATURES = {
 }
 LIBRARY_SYMBOLS = ["blgnn_version", "blgnn_last_error", "blgnn_device_count", "blgnn_packed_weight_x6_elems",
                    "blgnn_packed_weight_h3_elems", "blgnn_packed_weight_h3g_elems",
-                   "blgnn_col_reduce_scratch_elems"]
+                   "blgnn_col_reduce_scratch_elems", "blgnn_grad_weight_scratch_elems"]
 
 _lib = None
 
@@ -119,6 +120,8 @@ def load():
     lib.blgnn_packed_weight_h3g_elems.restype = ctypes.c_int64
     lib.blgnn_col_reduce_scratch_elems.argtypes = [_i32, _i32]
     lib.blgnn_col_reduce_scratch_elems.restype = ctypes.c_int64
+    lib.blgnn_grad_weight_scratch_elems.argtypes = [_i32, _i32, _i32]
+    lib.blgnn_grad_weight_scratch_elems.restype = ctypes.c_int64
     _lib = lib
     return lib
 

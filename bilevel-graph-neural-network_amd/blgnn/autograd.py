@@ -5,7 +5,7 @@ stack the forward path runs.  Here ``torch.autograd`` only records the graph and
 every arithmetic step of both directions is a kernel behind the C ABI:
 
   Linear (+act)      dX = g @ W            blgnn_linear on nn.Linear's own [out, in] weight
-                     dW = g^T @ X          blgnn_transpose + blgnn_linear (split-K over the rows)
+                     dW = g^T @ X          blgnn_grad_weight (row chunks on exact-f32 MFMA, fixed-order sum)
                      db = sum_rows g       blgnn_col_reduce;   g = dY * act'(Y): blgnn_act_backward
   GIN aggregation    same CSR, same op     blgnn_spmm_sum (molecular graphs are symmetric)
   BatchNorm1d train  statistics / dgamma / dbeta: blgnn_col_reduce; blgnn_bn_apply / blgnn_bn_backward
@@ -61,7 +61,7 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.linear(g, weight.contiguous(), transform="f32")              # [M, out] @ [out, in]
         if ctx.needs_input_grad[1]:
-            dw = ops.linear(ops.transpose(g), x.contiguous(), transform="f32")    # [out, M] @ [M, in]
+            dw = ops.grad_weight(g, x)                                            # sum_m g[m, out] x[m, in]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.col_reduce(g, "sum")
         return dx, dw, db, None
@@ -93,7 +93,7 @@ class _GatConv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.linear(dh, ops.transpose(weight.contiguous()), transform="f32")        # [n, out] @ [out, in]
         if ctx.needs_input_grad[1]:
-            dw = ops.linear(ops.transpose(x.contiguous()), dh, transform="f32")             # [in, n] @ [n, out]
+            dw = ops.grad_weight(x, dh)                                                     # [in, out]
         if ctx.needs_input_grad[2]:
             datt = ops.linear(ds, h, transform="f32").reshape(att.shape)                    # [2, n] @ [n, out]
         if ctx.needs_input_grad[3]:
@@ -125,7 +125,7 @@ class _GcnConv(torch.autograd.Function):
         g = dy if ctx.act == "identity" else ops.act_backward(dy, y, ctx.act)
         dh = ops.gcn_propagate(ctx.csr, g)
         dx = ops.linear(dh, ops.transpose(weight.contiguous()), transform="f32") if ctx.needs_input_grad[0] else None
-        dw = ops.linear(ops.transpose(x.contiguous()), dh, transform="f32") if ctx.needs_input_grad[1] else None
+        dw = ops.grad_weight(x, dh) if ctx.needs_input_grad[1] else None
         db = ops.col_reduce(g, "sum") if ctx.needs_input_grad[2] else None
         return dx, dw, db, None, None
 
@@ -160,13 +160,12 @@ class _MultiEdgeGat(torch.autograd.Function):
         saved = ctx.saved_tensors[2:]
         dy = dy.contiguous()
         g = dy if ctx.act == "identity" else ops.act_backward(dy, y, ctx.act)
-        xt = ops.transpose(x.contiguous())
         db = ops.col_reduce(g, "sum")                                     # every edge type's bias sees the same g
         grads, dhs, wts = [], [], []
         for k in range(ctx.K):
             w, a, h, sc, stats = saved[5 * k:5 * k + 5]
             dh, ds = ops.gat_backward(ctx.csrs[k], h, sc, stats, g, a, ctx.group, ctx.slope)
-            grads += [ops.linear(xt, dh, transform="f32"), ops.linear(ds, h, transform="f32").reshape(a.shape), db]
+            grads += [ops.grad_weight(x, dh), ops.linear(ds, h, transform="f32").reshape(a.shape), db]
             dhs.append(dh)
             wts.append(ops.transpose(w.contiguous()))
         dx = None

@@ -766,3 +766,18 @@ def gmn_match_backward(seg, x, du):
     call("blgnn_gmn_match_backward", _vec(seg, "seg", torch.int32, False), P, xp, ldx, gp, ldg, cell_off.data_ptr(),
          total_cells, cell_scratch.data_ptr(), row_scratch.data_ptr(), dx.data_ptr(), d, d, n, _stream())
     return dx
+
+
+def grad_weight(g, x):
+    """dw[o, i] = sum_m g[m, o] * x[m, i] over all rows (deterministic chunked reduction on the matrix cores)."""
+    gp, ldg = _mat(g, "g")
+    xp, ldx = _mat(x, "x")
+    M, O = g.shape
+    I = x.shape[1]
+    if x.shape[0] != M:
+        raise ValueError("blgnn: grad_weight operands differ in rows")
+    scratch = torch.empty(max(int(_lib.load().blgnn_grad_weight_scratch_elems(M, O, I)), 1), dtype=torch.float32,
+                          device=g.device)
+    dw = torch.empty((O, I), dtype=torch.float32, device=g.device)
+    call("blgnn_grad_weight", gp, ldg, xp, ldx, M, O, I, scratch.data_ptr(), dw.data_ptr(), _stream())
+    return dw

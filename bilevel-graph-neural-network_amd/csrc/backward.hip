@@ -168,6 +168,65 @@ __global__ void k_pair_scatter_add(const float *__restrict__ dcat, int64_t ldc, 
     unsafeAtomicAdd(dz + ids[b] * lddz + c, dcat[(int64_t)b * ldc + col0 + c]);
 }
 
+// dW[o, i] = sum_m g[m, o] x[m, i]  (the weight gradient of y = x W^T, nn.Linear layout [out, in]; also x^T dh for GATConv's
+// [in, out] weight with the operands swapped).  The reduction runs over ALL rows (tens of thousands of atoms) while the
+// output is tiny, so the rows are cut into chunks of GW_ROWS: one workgroup per (chunk, 128 x 128 output block) forms its
+// partial product with exact-f32 MFMA straight from the row-major operands (lane fi reads g[row, 32 to + fi] as the A
+// fragment and x[row, 32 ti + fi] as the B fragment: both coalesced, no transpose, no LDS), partials go to scratch and
+// k_col_final adds them in a fixed order (deterministic).  The forward GEMM kernels are shaped for the opposite case.
+constexpr int GW_ROWS = 1024;
+typedef float f32x16g __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(256) k_grad_weight(const float *__restrict__ g, int64_t ldg, const float *__restrict__ x,
+                                                     int64_t ldx, int M, int O, int I, float *__restrict__ partial) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int fi = lane & 31, fh = lane >> 5;
+    const int bi_n = (I + 127) / 128;
+    const int o0 = (blockIdx.y / bi_n) * 128 + (wid >> 1) * 64, i0 = (blockIdx.y % bi_n) * 128 + (wid & 1) * 64;
+    const int r0 = blockIdx.x * GW_ROWS, r1 = min(r0 + GW_ROWS, M);
+    f32x16g acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // columns outside the matrices are clamped (their products land in rows / columns that are never written)
+    const int oc[2] = {min(o0 + fi, O - 1), min(o0 + 32 + fi, O - 1)};
+    const int ic[2] = {min(i0 + fi, I - 1), min(i0 + 32 + fi, I - 1)};
+    if (o0 < O && i0 < I) {
+        // eight K steps (16 rows) of operands are requested before the first MFMA of the group: the loop is a chain of
+        // memory round trips otherwise (243 us per launch on 37 k rows; the products themselves need ~30 us)
+        for (int k = r0; k < r1; k += 16) {
+            float a0[8], a1[8], b0[8], b1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = min(k + 2 * u + fh, r1 - 1);
+                const float live = (k + 2 * u + fh) < r1 ? 1.f : 0.f;
+                const float *gr = g + (int64_t)row * ldg, *xr = x + (int64_t)row * ldx;
+                a0[u] = gr[oc[0]] * live; a1[u] = gr[oc[1]] * live; b0[u] = xr[ic[0]]; b1[u] = xr[ic[1]];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+    float *dst = partial + (int64_t)blockIdx.x * O * I;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * fh, i = i0 + 32 * b + fi;
+                if (o < O && i < I) dst[(int64_t)o * I + i] = acc[a][b][r];
+            }
+}
+
 static unsigned grid_for(int64_t items, int threads) { return (unsigned)((items + threads - 1) / threads); }
 
 }  // namespace blgnn
@@ -197,6 +256,23 @@ extern "C" int blgnn_col_reduce(const float *a, int64_t lda, const float *b, int
     }
     hipLaunchKernelGGL(k_col_final, dim3((N + 255) / 256), dim3(256), 0, s, scratch, chunks, N, scale, out);
     return launch_status("col_reduce");
+}
+
+extern "C" int64_t blgnn_grad_weight_scratch_elems(int32_t M, int32_t O, int32_t I) {
+    return (int64_t)((M + GW_ROWS - 1) / GW_ROWS) * O * I;
+}
+
+extern "C" int blgnn_grad_weight(const float *g, int64_t ldg, const float *x, int64_t ldx, int32_t M, int32_t O, int32_t I,
+                                 float *scratch, float *dw, void *stream) {
+    BLGNN_CHECK_ARG(M >= 0 && O > 0 && I > 0 && ldg >= O && ldx >= I, "grad_weight: bad sizes");
+    BLGNN_CHECK_ARG(g && x && scratch && dw, "grad_weight: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = (M + GW_ROWS - 1) / GW_ROWS;
+    if (chunks > 0)
+        hipLaunchKernelGGL(k_grad_weight, dim3(chunks, ((O + 127) / 128) * ((I + 127) / 128)), dim3(256), 0, s, g, ldg, x, ldx,
+                           M, O, I, scratch);
+    hipLaunchKernelGGL(k_col_final, dim3((O * I + 255) / 256), dim3(256), 0, s, scratch, chunks, O * I, 1.f, dw);
+    return launch_status("grad_weight");
 }
 
 extern "C" int blgnn_bn_apply(const float *x, int64_t ldx, const float *mean, const float *rstd, const float *gamma,

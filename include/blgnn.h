@@ -386,7 +386,7 @@ int blgnn_scatter_rows(const float *src, int64_t lds, const int32_t *row_map,
 /* ---- backward pass / train mode (src/train.py:177-182) -------------------- */
 /* The large products of the backward pass are the forward entry points on other operands:
  *   dX = dY @ W        -> blgnn_linear(dY, w_kn = nn.Linear.weight ([out, in] IS [K'=out, N'=in]))
- *   dW = dY^T @ X      -> blgnn_transpose(dY) then blgnn_linear(dY^T [out, M], w_kn = X [M, in])
+ *   dW = dY^T @ X      -> blgnn_grad_weight(dY, X)   (row-chunked reduction, below)
  *   GIN aggregation    -> blgnn_spmm_sum on the same (symmetric) CSR
  * The entry points below are the reductions and pointwise pieces around them. */
 
@@ -403,6 +403,14 @@ int64_t blgnn_col_reduce_scratch_elems(int32_t M, int32_t N);
 int blgnn_col_reduce(const float *a, int64_t lda, const float *b, int64_t ldb, const float *mean,
                      const float *rstd, int32_t M, int32_t N, int32_t mode, float scale,
                      float *scratch, float *out, void *stream);
+
+/* Weight gradient of a Linear over all rows: dw[o, i] = sum_m g[m, o] * x[m, i] (dw contiguous [O, I];
+ * nn.Linear's [out, in] layout for g = dY, x = X; GATConv's [in, out] with the operands swapped).
+ * Rows are reduced in chunks with exact-f32 MFMA, partials in scratch
+ * (blgnn_grad_weight_scratch_elems(M, O, I) floats), final sum in a fixed order: deterministic. */
+int64_t blgnn_grad_weight_scratch_elems(int32_t M, int32_t O, int32_t I);
+int blgnn_grad_weight(const float *g, int64_t ldg, const float *x, int64_t ldx, int32_t M, int32_t O,
+                      int32_t I, float *scratch, float *dw, void *stream);
 
 /* Train-mode BatchNorm1d forward: y = act((x - mean) * rstd * gamma + beta) (gamma / beta nullable;
  * act = the activation that follows the BatchNorm in MLP: model/layers_util.py:51-54). */
