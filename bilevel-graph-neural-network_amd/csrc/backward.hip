@@ -265,7 +265,7 @@ extern "C" int64_t blgnn_grad_weight_scratch_elems(int32_t M, int32_t O, int32_t
 extern "C" int blgnn_grad_weight(const float *g, int64_t ldg, const float *x, int64_t ldx, int32_t M, int32_t O, int32_t I,
                                  float *scratch, float *dw, void *stream) {
     BLGNN_CHECK_ARG(M >= 0 && O > 0 && I > 0 && ldg >= O && ldx >= I, "grad_weight: bad sizes");
-    BLGNN_CHECK_ARG(g && x && scratch && dw, "grad_weight: null pointer");
+    BLGNN_CHECK_ARG((M == 0 || (g && x)) && scratch && dw, "grad_weight: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int chunks = (M + GW_ROWS - 1) / GW_ROWS;
     if (chunks > 0)

@@ -446,3 +446,30 @@ def test_mhcaddi_gmn_training_step_gradients(device):
         assert max_err(p.grad, sd[name].grad) < TOL, name
         checked += 1
     assert checked >= 3 * 6 + 3 * 10
+
+
+@pytest.mark.parametrize("M,O,I", [(37001, 128, 128), (1, 5, 7), (1025, 130, 40), (2049, 64, 300), (16, 1, 1), (0, 8, 8)])
+def test_grad_weight_and_column_reductions_ragged_shapes(device, M, O, I):
+    """the row-chunked weight-gradient reduction and the deterministic column reductions: chunk edges (1 024 / 512
+    rows), output blocks that are not multiples of 32 / 128, a single row, no rows; strided operands"""
+    g = torch.Generator().manual_seed(M + O + I)
+    gw, xw = torch.randn(M, O + 3, generator=g), torch.randn(M, I + 5, generator=g)
+    gd, xd = gw.to(device)[:, 1:1 + O], xw.to(device)[:, 2:2 + I]           # column slices of wider buffers
+    ref = gw[:, 1:1 + O].double().t() @ xw[:, 2:2 + I].double()
+    got = ops.grad_weight(gd, xd)
+    assert got.shape == (O, I)
+    assert max_err(got, ref) < TOL
+    if M > 0:
+        a, b = gw[:, 1:1 + O].double(), torch.randn(M, O, generator=g).double()
+        mean = a.mean(0)
+        rstd = 1.0 / torch.sqrt(((a - mean) ** 2).mean(0) + 1e-5)
+        bd = b.float().to(device)
+        dv = lambda t: t.float().to(device).contiguous()
+        assert max_err(ops.col_reduce(gd, "sum"), a.sum(0)) < TOL
+        assert max_err(ops.col_reduce(gd, "dot", b=bd), (a * b).sum(0)) < TOL
+        assert max_err(ops.col_reduce(gd, "sqdev", mean=dv(mean)), ((a - mean) ** 2).sum(0)) < TOL
+        assert max_err(ops.col_reduce(bd, "dot_norm", b=gd, mean=dv(mean), rstd=dv(rstd)),
+                       (b * (a - mean) * rstd).sum(0)) < TOL
+        # bit-for-bit reproducible
+        assert torch.equal(ops.grad_weight(gd, xd), got)
+        assert torch.equal(ops.col_reduce(gd, "sum"), ops.col_reduce(gd, "sum"))
