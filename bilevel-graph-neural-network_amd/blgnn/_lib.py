@@ -37,9 +37,9 @@ SIGNATURES = {
     "blgnn_pack_weight_x6": [_p, _i64, _i32, _i32, _p, _p],
     "blgnn_pack_weight_h3": [_p, _i64, _i32, _i32, _p, _p],
     "blgnn_gin_layer_h3": [_p, _p, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _p, _i32, _f32, _i32, _p, _p, _p,
-                           _p, _i64, _p, _p, _p, _i64, _i32, _p],
+                           _p, _i64, _p, _p, _p, _i64, _i32, _p, _p],
     "blgnn_gin_layer_h3_codes": [_p, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p, _p, _i32, _f32, _i32, _p, _p, _p,
-                                 _p, _i64, _p, _p, _p, _i64, _i32, _p],
+                                 _p, _i64, _p, _p, _p, _i64, _i32, _p, _p],
     "blgnn_gin_layer_x6": [_p, _p, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _p, _i32, _f32, _i32, _p, _p, _p,
                            _p, _i64, _p],
     "blgnn_gin_stack": [_p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p,

@@ -207,8 +207,14 @@ class NodeEmbedding(nn.Module):
                     # dense transforms on the fp16 matrix cores at fp32 accuracy (scaled two-piece split)
                     w1p = self._cache.get("w1h", lambda w: ops.pack_weight_h3(w.t().contiguous()), lin1.weight)
                     w2p = self._cache.get("w2h", lambda w: ops.pack_weight_h3(w.t().contiguous()), lin2.weight)
+                    # (GMN models: the propagator's message GEMM normalises this output row by row; its row
+                    # magnitudes come out of this kernel's store loop instead of a pass over the result)
+                    amax = torch.empty(ins.shape[0], dtype=torch.float32, device=ins.device) if wide is not None else None
                     x = ops.gin_layer_h3(csr, ins, w1p, lin1.bias, w2p, lin2.bias, self.out_dim, eps=eps,
-                                         act=act, act_param=slopes, bn_scale=scale, bn_shift=shift, out=out, pool=pool)
+                                         act=act, act_param=slopes, bn_scale=scale, bn_shift=shift, out=out, pool=pool,
+                                         amax_out=amax)
+                    if amax is not None:
+                        x._blgnn_amax = amax
                     fused_pool = True
                 elif transform in ("bf16x6", "f16x3") and \
                         ops.gin_layer_x6_supported(csr, ins, ins.shape[1], self.out_dim):

@@ -127,7 +127,10 @@ class GMNPropagator(nn.Module):
                 with torch.cuda.stream(side):
                     ops.gmn_match(seg, x, out=f_in[:, 3 * D:])
             h3 = ops.linear_writes_amax(x, wpq)                           # the f16x3 GEMM takes row magnitudes
-            pq = ops.linear(x, wpq, bpq, row_amax=ops.row_absmax(x) if h3 else None)      # [n, 4D] = [P | Q]
+            ax = getattr(x, "_blgnn_amax", None) if h3 else None          # row magnitudes from the producing GIN layer
+            if h3 and ax is None:
+                ax = ops.row_absmax(x)
+            pq = ops.linear(x, wpq, bpq, row_amax=ax)                     # [n, 4D] = [P | Q]
             ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:], out=f_in[:, D:3 * D])
             if side is not None:
                 cur.wait_stream(side)

@@ -197,9 +197,10 @@ def _pool_args(pool, n, N):
 
 
 def gin_layer_h3(csr, x, w1_packed, b1, w2_packed, b2, N, eps=0.0, act="identity", act_param=None,
-                 bn_scale=None, bn_shift=None, out=None, pool=None):
+                 bn_scale=None, bn_shift=None, out=None, pool=None, amax_out=None):
     """blgnn_gin_layer with both GEMMs on the fp16 matrix cores at fp32 accuracy (f16x3).  ``pool``: fused
-    node -> graph readout of the result into a zero-initialised [G, N] view (see ``_pool_args``)."""
+    node -> graph readout of the result into a zero-initialised [G, N] view (see ``_pool_args``).  ``amax_out``
+    [n]: receives the row magnitudes of the result (for a following f16x3 GEMM)."""
     xp, ldx = _mat(x, "x")
     n, K = x.shape
     y = _out(out, n, N, x)
@@ -207,7 +208,7 @@ def gin_layer_h3(csr, x, w1_packed, b1, w2_packed, b2, N, eps=0.0, act="identity
     call("blgnn_gin_layer_h3", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, xp, ldx, n, K,
          w1_packed.data_ptr(), _vec(b1, "b1"), w2_packed.data_ptr(), _vec(b2, "b2"), N, float(eps), _act(act),
          _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), yp, ldy,
-         *_pool_args(pool, n, N), _stream())
+         *_pool_args(pool, n, N), _vec(amax_out, "amax_out"), _stream())
     return y
 
 
@@ -232,7 +233,7 @@ def gin_layer_h3_codes(csr, codes, offsets, w1_packed, b1, w2_packed, b2, N, eps
     call("blgnn_gin_layer_h3_codes", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, codes.data_ptr(), offs,
          len(offsets) - 1, n, w1_packed.data_ptr(), _vec(b1, "b1"), w2_packed.data_ptr(), _vec(b2, "b2"), N,
          float(eps), _act(act), _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"),
-         yp, ldy, *_pool_args(pool, n, N), _stream())
+         yp, ldy, *_pool_args(pool, n, N), None, _stream())
     return y
 
 

@@ -75,6 +75,7 @@ struct GinH3Args {
     const int32_t *row_graph, *seg;          // graph of every row (sorted) / graph row ranges [G + 1]
     float *pool; int64_t ldp;                // zero-initialised by the caller; nullptr = no readout
     int32_t pool_mean;                       // w = 1 / max(rows of the graph, 1), else 1
+    float *y_amax;                           // optional [n]: max |y[i, :]| per row (row scale of a following f16x3 GEMM)
 };
 
 // columns 4 l .. 4 l + 3 of the one-hot row of an atom
@@ -414,11 +415,20 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
     for (int idx = threadIdx.x; idx < XBM * N4; idx += NTH) {
         const int m = idx / N4, c4 = idx % N4;
         const int row = m0 + m;
-        if (row >= A.n) continue;
+        const bool live = row < A.n;
         const float4 v = *reinterpret_cast<const float4 *>(Ys + m * LDO + 4 * c4);
-        float *dst = A.y + (int64_t)row * A.ldy + 4 * c4;
-        if (vec_out) *reinterpret_cast<float4 *>(dst) = v;
-        else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
+        if (live) {
+            float *dst = A.y + (int64_t)row * A.ldy + 4 * c4;
+            if (vec_out) *reinterpret_cast<float4 *>(dst) = v;
+            else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
+        }
+        if (A.y_amax) {
+            // the N4 lanes that store one row sit in one wavefront (N4 = 32 or 64): their maximum is the row's
+            float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+#pragma unroll
+            for (int off = 1; off < N4; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, WAVE));
+            if (live && c4 == 0) A.y_amax[row] = mx;
+        }
     }
     // ---- (4) fused readout: per-graph column sums of the staged tile, one atomic per (graph, column) and tile.
     // Rows are sorted by graph, so a tile touches few graphs (DrugBank: 27 atoms per molecule, ~2 per tile) and a
@@ -560,7 +570,7 @@ extern "C" int blgnn_gin_layer_h3(const int32_t *rowptr, const int32_t *col, int
                                   const void *w2_packed, const float *b2, int32_t N, float eps, int32_t act,
                                   const float *act_param, const float *bn_scale, const float *bn_shift,
                                   float *y, int64_t ldy, const int32_t *row_graph, const int32_t *seg,
-                                  float *pooled, int64_t ldp, int32_t pool_kind, void *stream) {
+                                  float *pooled, int64_t ldp, int32_t pool_kind, float *y_row_amax, void *stream) {
     BLGNN_CHECK_ARG(n >= 0 && K > 0 && N > 0 && nnz >= 0, "gin_layer_h3: bad sizes");
     BLGNN_CHECK_ARG(!pooled || (row_graph && seg && ldp >= N && (pool_kind == BLGNN_REDUCE_SUM || pool_kind == BLGNN_REDUCE_MEAN)),
                     "gin_layer_h3: fused readout needs row_graph, seg, ldp >= N and a reduce kind");
@@ -581,6 +591,7 @@ extern "C" int blgnn_gin_layer_h3(const int32_t *rowptr, const int32_t *col, int
     A.y = y; A.ldy = ldy;
     A.codes = nullptr; A.n_attr = 0;
     A.row_graph = row_graph; A.seg = seg; A.pool = pooled; A.ldp = ldp; A.pool_mean = pool_kind == BLGNN_REDUCE_MEAN;
+    A.y_amax = y_row_amax;
     hipStream_t s = (hipStream_t)stream;
     const int k4 = K / 4;
     if (N == 256) {
@@ -598,7 +609,7 @@ extern "C" int blgnn_gin_layer_h3_codes(const int32_t *rowptr, const int32_t *co
                                         const float *b2, int32_t N, float eps, int32_t act, const float *act_param,
                                         const float *bn_scale, const float *bn_shift, float *y, int64_t ldy,
                                         const int32_t *row_graph, const int32_t *seg, float *pooled, int64_t ldp,
-                                        int32_t pool_kind, void *stream) {
+                                        int32_t pool_kind, float *y_row_amax, void *stream) {
     BLGNN_CHECK_ARG(!pooled || (row_graph && seg && ldp >= N && (pool_kind == BLGNN_REDUCE_SUM || pool_kind == BLGNN_REDUCE_MEAN)),
                     "gin_layer_h3_codes: fused readout needs row_graph, seg, ldp >= N and a reduce kind");
     BLGNN_CHECK_ARG(n >= 0 && N > 0 && nnz >= 0 && num_attr >= 1 && num_attr <= 8 && code_offsets_host,
@@ -619,6 +630,7 @@ extern "C" int blgnn_gin_layer_h3_codes(const int32_t *rowptr, const int32_t *co
     A.y = y; A.ldy = ldy;
     A.codes = reinterpret_cast<const uint2 *>(codes); A.n_attr = num_attr;
     A.row_graph = row_graph; A.seg = seg; A.pool = pooled; A.ldp = ldp; A.pool_mean = pool_kind == BLGNN_REDUCE_MEAN;
+    A.y_amax = y_row_amax;
     for (int a = 0; a < 8; ++a) {
         const int o = a < num_attr ? code_offsets_host[a] : 0;
         BLGNN_CHECK_ARG(o >= 0 && o < 256, "gin_layer_h3_codes: attribute offset out of range");

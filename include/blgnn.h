@@ -146,7 +146,9 @@ int blgnn_gin_layer_x6(const int32_t *rowptr, const int32_t *col, int64_t nnz,
  * (row_graph = the sorted batch vector as int32[n], seg = graph row ranges int32[G+1], pooled
  * ZERO-INITIALISED by the caller, typically a column slice of the multi-scale readout buffer).
  * One hardware float atomic per (graph, column, tile): a graph covered by <= 2 tiles sums in an
- * order-independent way; larger ones may differ in the last bit between runs.  pooled == NULL: off. */
+ * order-independent way; larger ones may differ in the last bit between runs.  pooled == NULL: off.
+ * y_row_amax (optional, [n]): receives max |y[i, :]| of every row -- the row magnitudes a following
+ * blgnn_linear_h3 on y normalises by (the GMN message GEMM), without a pass over y. */
 int64_t blgnn_packed_weight_h3_elems(int32_t K, int32_t N);
 int blgnn_pack_weight_h3(const float *w, int64_t ldw, int32_t K, int32_t N, void *out,
                          void *stream);
@@ -157,7 +159,7 @@ int blgnn_gin_layer_h3(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                        const float *act_param, const float *bn_scale,
                        const float *bn_shift, float *y, int64_t ldy, const int32_t *row_graph,
                        const int32_t *seg, float *pooled, int64_t ldp, int32_t pool_kind,
-                       void *stream);
+                       float *y_row_amax, void *stream);
 
 /* blgnn_gin_layer_h3 for the FIRST lower layer with categorical input: instead of the one-hot rows
  * x[n, F_in] (utils/data/representation_node_feat.py:86-97: one block per attribute, one 1 per block)
@@ -172,7 +174,8 @@ int blgnn_gin_layer_h3_codes(const int32_t *rowptr, const int32_t *col, int64_t 
                              int32_t N, float eps, int32_t act, const float *act_param,
                              const float *bn_scale, const float *bn_shift, float *y,
                              int64_t ldy, const int32_t *row_graph, const int32_t *seg,
-                             float *pooled, int64_t ldp, int32_t pool_kind, void *stream);
+                             float *pooled, int64_t ldp, int32_t pool_kind, float *y_row_amax,
+                             void *stream);
 
 /* The whole lower level in ONE launch: num_layers (<= 8) stacked GIN NodeEmbedding layers
  * (model/layers.py:26-31,51-57) + the node -> graph readout of every layer that is pooled

@@ -154,10 +154,12 @@ def test_gin_layer_f16x3(device, K, act, N):
     assert ops.gin_layer_h3_supported(csr, dv(x), K, N)
     w1p, w2p = ops.pack_weight_h3(dv(w1.t().contiguous())), ops.pack_weight_h3(dv(w2.t().contiguous()))
     wide = torch.zeros(n, N + 8, device=device)
+    amax = torch.full((n,), -1.0, device=device)
     got = ops.gin_layer_h3(csr, dv(x), w1p, dv(b1), w2p, dv(b2), N, eps=0.25, act=act, act_param=dv(slope),
-                           bn_scale=dv(scale), bn_shift=dv(shift), out=wide[:, 4:4 + N])
+                           bn_scale=dv(scale), bn_shift=dv(shift), out=wide[:, 4:4 + N], amax_out=amax)
     assert max_err(got, ref) < TOL
     assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + N:].abs().max()) == 0.0
+    assert torch.equal(amax, got.abs().amax(dim=1))          # row magnitudes out of the store loop
 
 
 @pytest.mark.parametrize("N,kind,sizes", [(128, "mean", None), (128, "sum", None), (256, "mean", None),
