@@ -98,6 +98,9 @@ def parse():
                          "(molecular sweep with gradients -> interaction level -> BCE -> backward -> SGD; "
                          "src/train.py:75-108,177-182) and print one JSON line for them")
     ap.add_argument("--readout-with-upper", action="store_true")
+    ap.add_argument("--gmn-fused-amax", action="store_true",
+                    help="GMN configs: the producers of the f_node input merge its row magnitudes (atomic maximum) instead "
+                         "of a pass over it (measured: no gain)")
     ap.add_argument("--gmn-streams", type=int, default=1,
                     help="GMN configs: consecutive steps (independent pair batches) alternate over this many streams")
     ap.add_argument("--no-fuse-readout", action="store_true",
@@ -570,6 +573,7 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
                               num_edge_types=cfg["edge_types"])
     flags = blgnn.make_flags("lower_level_gmn", dataset=cfg["dataset"], lower_level_gnn_type="gin", D_lower=d,
                              device=device, batch_size=batch, feature_transform=transform)
+    flags.gmn_fused_amax = bool(getattr(args, "gmn_fused_amax", False))
     blgnn.set_flags(flags)
     torch.manual_seed(seed)
     data = blgnn.TrainData(ds, device=device, num_hyper_edge_feat=3 if cfg["edge_types"] > 1 else 0)

@@ -52,7 +52,7 @@ SIGNATURES = {
     "blgnn_gat_softmax_stats": [_p, _p, _i64, _p, _p, _i32, _i32, _f32, _p, _p, _p],
     "blgnn_gat_aggregate": [_p, _p, _i64, _p, _i64, _p, _p, _p, _p, _i32, _f32, _p, _i64, _i32, _i32,
                             _p, _i32, _p, _p, _p, _i32, _p],
-    "blgnn_edge_relu_sum": [_p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p],
+    "blgnn_edge_relu_sum": [_p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _p],
     "blgnn_row_degree": [_p, _i32, _p, _p],
     "blgnn_segment_reduce": [_p, _i32, _p, _i64, _i32, _i32, _p, _i64, _p, _p],
     "blgnn_segment_reduce_multi": [_p, _i32, _i32, _p, _p, _p, _i32, _p, _i64, _p, _p],
@@ -62,7 +62,7 @@ SIGNATURES = {
     "blgnn_pack_weight_h3g": [_p, _i64, _i32, _i32, _p, _p],
     "blgnn_row_absmax": [_p, _i64, _i32, _i32, _p, _p],
     "blgnn_linear_h3": [_p, _i64, _p, _p, _p, _i64, _p, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p, _p],
-    "blgnn_gmn_match": [_p, _i32, _p, _i64, _p, _i64, _i32, _p],
+    "blgnn_gmn_match": [_p, _i32, _p, _i64, _p, _i64, _i32, _p, _p],
     "blgnn_pair_gather_normalize": [_p, _i64, _p, _p, _i32, _i32, _f32, _p, _i64, _p],
     "blgnn_link_pred_head": [_p, _i64, _p, _p, _i32, _i32, _f32, _i32, _p, _p, _p, _i32, _i32, _p, _i64, _p],
     "blgnn_l2_normalize_rows": [_p, _i64, _p, _i64, _i32, _i32, _f32, _p],

@@ -121,27 +121,34 @@ class GMNPropagator(nn.Module):
             # after the GEMM, next to the edge kernel only, gained nothing).
             side = self._side_stream(x.device) if (x.is_cuda and getattr(FLAGS, "gmn_overlap_match", True)) else None
             seg = merge.segments()                               # (built on the launch stream, before the fork)
-            if side is not None:
-                cur = torch.cuda.current_stream(x.device)
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    ops.gmn_match(seg, x, out=f_in[:, 3 * D:])
-            h3 = ops.linear_writes_amax(x, wpq)                           # the f16x3 GEMM takes row magnitudes
-            ax = getattr(x, "_blgnn_amax", None) if h3 else None          # row magnitudes from the producing GIN layer
+            h3 = ops.linear_writes_amax(x, wpq)                           # the f16x3 GEMMs take row magnitudes
+            ax = getattr(x, "_blgnn_amax", None) if h3 else None          # ... of x: from the producing GIN layer
             if h3 and ax is None:
                 ax = ops.row_absmax(x)
-            pq = ops.linear(x, wpq, bpq, row_amax=ax)                     # [n, 4D] = [P | Q]
-            ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:], out=f_in[:, D:3 * D])
-            if side is not None:
-                cur.wait_stream(side)
-            else:
-                ops.gmn_match(seg, x, out=f_in[:, 3 * D:])
             act = act_name(self.f_node.activation)
             hid_amax = None
             if ops.linear_writes_amax(f_in, w1):
                 hid_amax = torch.zeros(n, dtype=torch.float32, device=x.device)
-            hid = ops.linear(f_in, w1, b1, act=act, rowvec=ops.row_degree(csr), rowvec_w=rw, amax_out=hid_amax,
-                             row_amax=ops.row_absmax(f_in) if hid_amax is not None else None)
+            # ... of f_in = [x | S | u]: one pass over the [n, 4D] buffer -- or (FLAGS.gmn_fused_amax) merged by the
+            # producers of S and u themselves, by atomic maximum into a copy of x's.  Exact either way; measured
+            # 24.63 / 24.72 vs 24.54 / 24.62 ms per step at configs[2]: the attention kernels cannot share a CU with the
+            # GEMM (LDS), so they sit on the critical path behind it and the row reductions added to them cost what the
+            # removed pass saved.  Off by default.
+            af = ax.clone() if (hid_amax is not None and ax is not None and getattr(FLAGS, "gmn_fused_amax", False)) else None
+            if side is not None:
+                cur = torch.cuda.current_stream(x.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    ops.gmn_match(seg, x, out=f_in[:, 3 * D:], row_amax=af)
+            pq = ops.linear(x, wpq, bpq, row_amax=ax)                     # [n, 4D] = [P | Q]
+            ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:], out=f_in[:, D:3 * D], row_amax=af)
+            if side is not None:
+                cur.wait_stream(side)
+            else:
+                ops.gmn_match(seg, x, out=f_in[:, 3 * D:], row_amax=af)
+            if af is None and hid_amax is not None:
+                af = ops.row_absmax(f_in)
+            hid = ops.linear(f_in, w1, b1, act=act, rowvec=ops.row_degree(csr), rowvec_w=rw, amax_out=hid_amax, row_amax=af)
             out = ops.linear(hid, self.f_node.weight_kn(1), self.f_node.layers[1].bias, row_amax=hid_amax)
         model.store_layer_output(self, out)
         return out

@@ -535,7 +535,8 @@ def segment_reduce_multi(seg, xs, kind="mean", row_map=None, out=None):
     return out
 
 
-def gmn_match(seg, x, out=None):
+def gmn_match(seg, x, out=None, row_amax=None):
+    """``row_amax`` [rows]: merged with the row magnitudes of the result (atomic maximum)."""
     xp, ldx = _mat(x, "x")
     G = seg.numel() - 1
     if G % 2:
@@ -543,18 +544,19 @@ def gmn_match(seg, x, out=None):
     u = _out(out, x.shape[0], x.shape[1], x)
     up, ldu = _mat(u, "out")
     call("blgnn_gmn_match", _vec(seg, "seg", torch.int32, False), G // 2, xp, ldx, up, ldu,
-         x.shape[1], _stream())
+         x.shape[1], _vec(row_amax, "row_amax"), _stream())
     return u
 
 
-def edge_relu_sum(csr, p, q, out=None):
+def edge_relu_sum(csr, p, q, out=None, row_amax=None):
+    """``row_amax`` [n]: merged with the row maxima of the result (atomic maximum)."""
     pp, ldp = _mat(p, "p")
     qp, ldq = _mat(q, "q")
     n, d = p.shape
     y = _out(out, n, d, p)
     yp, ldy = _mat(y, "out")
     call("blgnn_edge_relu_sum", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, pp, ldp, qp, ldq, yp,
-         ldy, n, d, _stream())
+         ldy, n, d, _vec(row_amax, "row_amax"), _stream())
     return y
 
 

@@ -40,6 +40,7 @@ struct GatherArgs {
     // RELU
     const float *p;
     int64_t ldp;
+    float *amax;         // optional [n]: atomic max of the result row's magnitudes into it (k_gather only)
     // epilogue
     Epilogue epi;
     int32_t accumulate;
@@ -161,6 +162,16 @@ __global__ void __launch_bounds__(256) k_gather(const GatherArgs A) {
             }
         }
         float4 *Y = reinterpret_cast<float4 *>(A.y) + (int64_t)row * ldy4;
+        if (MODE == MODE_RELU && A.amax) {
+            // sums of relus are non-negative: the row maximum over the LG lanes of the row, one atomic per row
+            float mx = 0.f;
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (ok[k]) mx = fmaxf(mx, fmaxf(fmaxf(acc[k].x, acc[k].y), fmaxf(acc[k].z, acc[k].w)));
+#pragma unroll
+            for (int off = 1; off < LG; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, WAVE));
+            if (l == 0) atomicMax(reinterpret_cast<unsigned *>(A.amax) + row, __float_as_uint(mx));
+        }
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
             if (!ok[k]) continue;
@@ -649,8 +660,22 @@ static void launch_wide(const GatherArgs &A, hipStream_t s) {
 // rows this heavy on average go one-workgroup-per-row (see k_gather_wide)
 constexpr int64_t WIDE_MEAN_DEGREE = 12;
 
+// row magnitudes of a finished result merged into amax by atomic maximum (fallback of the variants without an amax epilogue)
+__global__ void __launch_bounds__(256) k_row_absmax_merge(const float *__restrict__ y, int64_t ldy, int n, int d,
+                                                          float *__restrict__ amax) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int row = blockIdx.x * 4 + threadIdx.x / WAVE;
+    if (row >= n) return;
+    float m = 0.f;
+    for (int c = lane; c < d; c += WAVE) m = fmaxf(m, fabsf(y[(int64_t)row * ldy + c]));
+    m = group_max(m, WAVE);
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(amax) + row, __float_as_uint(m));
+}
+
 template <int MODE>
-static int dispatch(const GatherArgs &A, int64_t nnz, bool extra_aligned, hipStream_t s, const char *what) {
+static int dispatch(const GatherArgs &A, int64_t nnz, bool extra_aligned, hipStream_t s, const char *what,
+                    bool *amax_native = nullptr) {
+    if (amax_native) *amax_native = false;
     if (A.n == 0 || A.d == 0) return BLGNN_OK;
     const bool vec = (A.d % 4 == 0) && (A.ldx % 4 == 0) && (A.ldy % 4 == 0) &&
                      aligned16(A.x) && aligned16(A.y) && extra_aligned;
@@ -673,6 +698,7 @@ static int dispatch(const GatherArgs &A, int64_t nnz, bool extra_aligned, hipStr
         else if (d4 <= 32) launch_rows4<MODE, 32>(A, s);
         else launch_rows4<MODE, 64>(A, s);
     } else if (vec && d4 <= 512) {
+        if (amax_native) *amax_native = true;
         if (d4 <= 16) launch_vec<MODE, 16, 1>(A, s);
         else if (d4 <= 32) launch_vec<MODE, 32, 1>(A, s);
         else if (d4 <= 64) launch_vec<MODE, 64, 1>(A, s);
@@ -881,7 +907,7 @@ extern "C" int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col, in
 
 extern "C" int blgnn_edge_relu_sum(const int32_t *rowptr, const int32_t *col, int64_t nnz, const float *p,
                                    int64_t ldp, const float *q, int64_t ldq, float *y,
-                                   int64_t ldy, int32_t n, int32_t d, void *stream) {
+                                   int64_t ldy, int32_t n, int32_t d, float *row_amax, void *stream) {
     if (int rc = check_csr(rowptr, col, n, nnz, "edge_relu_sum")) return rc;
     BLGNN_CHECK_ARG(d >= 0 && (n == 0 || d == 0 || (p && q && y)), "edge_relu_sum: null pointer");
     BLGNN_CHECK_ARG(ldp >= d && ldq >= d && ldy >= d, "edge_relu_sum: leading dimension < d");
@@ -889,6 +915,11 @@ extern "C" int blgnn_edge_relu_sum(const int32_t *rowptr, const int32_t *col, in
     GatherArgs A = {};
     A.rowptr = rowptr; A.col = col; A.x = q; A.ldx = ldq; A.y = y; A.ldy = ldy; A.n = n; A.d = d;
     A.p = p; A.ldp = ldp;
+    A.amax = row_amax;
     const bool pa = (ldp % 4 == 0) && aligned16(p);
-    return dispatch<MODE_RELU>(A, nnz, pa, (hipStream_t)stream, "edge_relu_sum");
+    bool native = false;
+    const int rc = dispatch<MODE_RELU>(A, nnz, pa, (hipStream_t)stream, "edge_relu_sum", &native);
+    if (rc != BLGNN_OK || !row_amax || native || n == 0 || d == 0) return rc;
+    hipLaunchKernelGGL(k_row_absmax_merge, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, y, ldy, n, d, row_amax);
+    return launch_status("edge_relu_sum");
 }

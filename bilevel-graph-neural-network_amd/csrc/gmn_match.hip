@@ -17,7 +17,7 @@ template <int CH>
 __global__ void __launch_bounds__(512)
 k_gmn_match(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__restrict__ x,
             int64_t ldx, float *__restrict__ u, int64_t ldu, int32_t d, int32_t lds_floats, int32_t skip_small,
-            int32_t parts) {
+            int32_t parts, float *__restrict__ amax) {
     extern __shared__ float4 smem4[];
     float *smem = reinterpret_cast<float *>(smem4);
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
@@ -116,6 +116,7 @@ k_gmn_match(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__r
             }
             const float invl = nb > 0 ? 1.f / l_run : 0.f;
             float *urow = u + (int64_t)arow_g * ldu;
+            float rmx = 0.f;
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 const int c4 = lane + k * WAVE;
@@ -125,7 +126,12 @@ k_gmn_match(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__r
                     r.x = a.x - acc[k].x * invl; r.y = a.y - acc[k].y * invl;
                     r.z = a.z - acc[k].z * invl; r.w = a.w - acc[k].w * invl;
                     *reinterpret_cast<float4 *>(urow + 4 * c4) = r;
+                    rmx = fmaxf(rmx, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
                 }
+            }
+            if (amax) {
+                rmx = group_max(rmx, WAVE);
+                if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(amax) + arow_g, __float_as_uint(rmx));
             }
         }
     };
@@ -217,7 +223,7 @@ __device__ __forceinline__ void match_norms(float (&nsq)[8], const float4 (&pre)
 template <bool TRANS, int ELD>
 __device__ __forceinline__ void match_u_tile(const float *E, const float *isum, const float *own, const float *partner, int rt, int ct,
                                              int kmax, int nrows, int row0, int64_t ldu, int c, __amdgpu_buffer_rsrc_t RU,
-                                             unsigned uvoff, int fi, int fh) {
+                                             unsigned uvoff, int fi, int fh, unsigned *umax) {
     const float *er = TRANS ? E + fh * ELD + 32 * rt + fi : E + (32 * rt + fi) * ELD + fh;
     const float *br = partner + fh * MLD + 32 * ct + fi;
     f32x16m o;
@@ -229,16 +235,21 @@ __device__ __forceinline__ void match_u_tile(const float *E, const float *isum, 
     for (int r = 0; r < 16; ++r) {
         const int rc = 32 * rt + (r & 3) + 8 * (r >> 2);                  // + 4 fh = row inside the graph
         const unsigned soff = (unsigned)((row0 + rc) * ldu + c * MCH + 32 * ct) * 4u;
-        if (rc + 4 * fh < nrows)
-            __builtin_amdgcn_raw_buffer_store_b32(
-                __builtin_bit_cast(unsigned int, own[(rc + 4 * fh) * MLD + 32 * ct + fi] - o[r] * isum[rc + 4 * fh]), RU, uvoff,
-                soff, 0);
+        const float val = own[(rc + 4 * fh) * MLD + 32 * ct + fi] - o[r] * isum[rc + 4 * fh];
+        if (rc + 4 * fh < nrows) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, val), RU, uvoff, soff, 0);
+        if (umax) {
+            // row magnitude: the 32 lanes of a half-wave hold 32 columns of row rc + 4 fh; one LDS atomic per row and tile
+            float mx = fabsf(val);
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, WAVE));
+            if (fi == 0 && rc + 4 * fh < nrows) atomicMax(umax + row0 + rc + 4 * fh, __float_as_uint(mx));
+        }
     }
 }
 
 __global__ void __launch_bounds__(256, 2)
 k_gmn_match_mfma(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__restrict__ x, int64_t ldx,
-                 float *__restrict__ u, int64_t ldu, int32_t d) {
+                 float *__restrict__ u, int64_t ldu, int32_t d, float *__restrict__ amax) {
     extern __shared__ float4 smem4[];
     float *R0 = reinterpret_cast<float *>(smem4);       // pass 1: G1 chunk | partial 2
     float *R1 = R0 + MREG;                              // pass 1: G2 chunk | partial 3 ; pass 2: G2 chunk
@@ -246,6 +257,7 @@ k_gmn_match_mfma(const int32_t *__restrict__ seg, int32_t num_pairs, const float
     float *R3 = R2 + MREG;                              // partial 1 ; pass 2: G1 chunk
     float *inv = R3 + MREG;                             // [2 MM] 1 / max(|row|, eps)
     float *ril = inv + 2 * MM, *cil = ril + MM;         // 1 / row sums, 1 / column sums of E
+    unsigned *umx = reinterpret_cast<unsigned *>(cil + MM);   // [2 MM] row magnitudes of the pair's result (float bits)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fi = lane & 31, fh = lane >> 5;
     const int lrow = tid >> 4, lc4 = tid & 15;          // chunk loads: 16 threads x 16 B per row, 16 rows per pass
@@ -350,6 +362,8 @@ k_gmn_match_mfma(const int32_t *__restrict__ seg, int32_t num_pairs, const float
             float l = 0.f;
             for (int i = 0; i < n1; ++i) l += R2[i * MLD + j];
             cil[j] = (j < n2 && n1 > 0) ? 1.f / l : 0.f;
+        } else if (tid < 4 * MM) {
+            umx[tid - 2 * MM] = 0u;
         }
         // ---- pass 2: U1 = G1 - A G2 (waves 0, 1), U2 = G2 - A' G1 (waves 2, 3), 32 columns per wave ---------------
         const bool second = wid >= 2;
@@ -358,11 +372,11 @@ k_gmn_match_mfma(const int32_t *__restrict__ seg, int32_t num_pairs, const float
             if (!second) {
 #pragma unroll 1
                 for (int i = 0; i < 2; ++i)
-                    if (i < TM) match_u_tile<false, MLD>(R2, ril, R3, R1, i, ct, 32 * TN, n1, 0, ldu, c, RU, uvoff, fi, fh);
+                    if (i < TM) match_u_tile<false, MLD>(R2, ril, R3, R1, i, ct, 32 * TN, n1, 0, ldu, c, RU, uvoff, fi, fh, amax ? umx : nullptr);
             } else {
 #pragma unroll 1
                 for (int i = 0; i < 2; ++i)
-                    if (i < TN) match_u_tile<true, MLD>(R2, cil, R1, R3, i, ct, 32 * TM, n2, n1, ldu, c, RU, uvoff, fi, fh);
+                    if (i < TN) match_u_tile<true, MLD>(R2, cil, R1, R3, i, ct, 32 * TM, n2, n1, ldu, c, RU, uvoff, fi, fh, amax ? umx : nullptr);
             }
         };
         for (int c = 0; c < nch; ++c) {
@@ -372,18 +386,23 @@ k_gmn_match_mfma(const int32_t *__restrict__ seg, int32_t num_pairs, const float
             __syncthreads();
             u_chunk(c);
         }
+        if (amax) {                                            // the pair's row magnitudes -> global (atomic maximum)
+            __syncthreads();
+            if (tid < n1 + n2) atomicMax(reinterpret_cast<unsigned *>(amax) + s0 + tid, umx[tid]);
+        }
     }
 }
 
 __global__ void __launch_bounds__(512)
 k_gmn_match_mfma_big(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__restrict__ x, int64_t ldx,
-                     float *__restrict__ u, int64_t ldu, int32_t d) {
+                     float *__restrict__ u, int64_t ldu, int32_t d, float *__restrict__ amax) {
     extern __shared__ float4 smem4[];
     float *E = reinterpret_cast<float *>(smem4);        // [BM][BLD]
     float *G1c = E + BM * BLD;                          // [BM][MLD]
     float *G2c = G1c + BM * MLD;                        // [BM][MLD]
     float *inv = G2c + BM * MLD;                        // [2 BM] 1 / max(|row|, eps)
     float *ril = inv + 2 * BM, *cil = ril + BM;         // 1 / row sums, 1 / column sums of E
+    unsigned *umx = reinterpret_cast<unsigned *>(cil + BM);   // [2 BM] row magnitudes of the pair's result (float bits)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fi = lane & 31, fh = lane >> 5;
     const int lrow = tid >> 4, lc4 = tid & 15;          // chunk loads: 16 threads x 16 B per row, 32 rows per pass
@@ -487,12 +506,14 @@ k_gmn_match_mfma_big(const int32_t *__restrict__ seg, int32_t num_pairs, const f
             float l = 0.f;
             for (int i = 0; i < n1; ++i) l += E[i * BLD + j];
             cil[j] = (j < n2 && n1 > 0) ? 1.f / l : 0.f;
+        } else {
+            umx[tid - 2 * BM] = 0u;                            // threads 256 .. 511 = the 2 BM entries
         }
         // ---- pass 2: per chunk one U1 tile (rows 32 (wid >> 1), columns 32 (wid & 1)) and one U2 tile per wave ----
         const int rt = wid >> 1, ct = wid & 1;
         auto u_chunk = [&](int c) {
-            if (rt < TM) match_u_tile<false, BLD>(E, ril, G1c, G2c, rt, ct, 32 * TN, n1, 0, ldu, c, RU, uvoff, fi, fh);
-            if (rt < TN) match_u_tile<true, BLD>(E, cil, G2c, G1c, rt, ct, 32 * TM, n2, n1, ldu, c, RU, uvoff, fi, fh);
+            if (rt < TM) match_u_tile<false, BLD>(E, ril, G1c, G2c, rt, ct, 32 * TN, n1, 0, ldu, c, RU, uvoff, fi, fh, amax ? umx : nullptr);
+            if (rt < TN) match_u_tile<true, BLD>(E, cil, G2c, G1c, rt, ct, 32 * TM, n2, n1, ldu, c, RU, uvoff, fi, fh, amax ? umx : nullptr);
         };
         for (int c = 0; c < nch; c += 2) {
             __syncthreads();                                   // sums written / previous chunk consumed
@@ -509,6 +530,7 @@ k_gmn_match_mfma_big(const int32_t *__restrict__ seg, int32_t num_pairs, const f
             }
         }
         __syncthreads();                                       // E / chunks free for the next pair
+        if (amax && tid < n1 + n2) atomicMax(reinterpret_cast<unsigned *>(amax) + s0 + tid, umx[tid]);
     }
 }
 
@@ -517,7 +539,7 @@ k_gmn_match_mfma_big(const int32_t *__restrict__ seg, int32_t num_pairs, const f
 using namespace blgnn;
 
 extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const float *x, int64_t ldx,
-                               float *u, int64_t ldu, int32_t d, void *stream) {
+                               float *u, int64_t ldu, int32_t d, float *row_amax, void *stream) {
     BLGNN_CHECK_ARG(num_pairs >= 0 && d >= 0, "gmn_match: negative size");
     if (num_pairs == 0 || d == 0) return BLGNN_OK;
     BLGNN_CHECK_ARG(seg && x && u, "gmn_match: null pointer");
@@ -535,7 +557,7 @@ extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const floa
     int skip_small = -1;
     if (d % MCH == 0) {                                    // matrix-core kernel for pairs up to 64 x 64 nodes
         static bool declared = false;
-        const int mbytes = (4 * MREG + 4 * MM) * (int)sizeof(float);
+        const int mbytes = (4 * MREG + 6 * MM) * (int)sizeof(float);
         if (!declared) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gmn_match_mfma),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, mbytes) != hipSuccess)
@@ -543,12 +565,12 @@ extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const floa
             declared = true;
         }
         const int mblocks = num_pairs < 256 * 8 ? num_pairs : 256 * 8;
-        hipLaunchKernelGGL(k_gmn_match_mfma, dim3(mblocks), dim3(256), mbytes, s, seg, num_pairs, x, ldx, u, ldu, d);
+        hipLaunchKernelGGL(k_gmn_match_mfma, dim3(mblocks), dim3(256), mbytes, s, seg, num_pairs, x, ldx, u, ldu, d, row_amax);
         int rc = launch_status("gmn_match");
         if (rc != BLGNN_OK) return rc;
         // pairs with a graph of 65 .. 128 nodes: one 512-thread workgroup each, S resident in LDS
         static bool declared_big = false;
-        const int bbytes = (BM * BLD + 2 * BM * MLD + 4 * BM) * (int)sizeof(float);
+        const int bbytes = (BM * BLD + 2 * BM * MLD + 6 * BM) * (int)sizeof(float);
         if (!declared_big) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gmn_match_mfma_big),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, bbytes) != hipSuccess)
@@ -556,7 +578,7 @@ extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const floa
             declared_big = true;
         }
         hipLaunchKernelGGL(k_gmn_match_mfma_big, dim3((num_pairs + BIG_PPW - 1) / BIG_PPW), dim3(512), bbytes, s, seg, num_pairs,
-                           x, ldx, u, ldu, d);
+                           x, ldx, u, ldu, d, row_amax);
         rc = launch_status("gmn_match");
         if (rc != BLGNN_OK) return rc;
         skip_small = BM;
@@ -581,7 +603,7 @@ extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const floa
             declared = lds_bytes;                                                                   \
         }                                                                                           \
         hipLaunchKernelGGL((k_gmn_match<CH_>), dim3(blocks), dim3(threads), lds_bytes, s, seg,      \
-                           num_pairs, x, ldx, u, ldu, d, lds_floats, skip_small, parts);           \
+                           num_pairs, x, ldx, u, ldu, d, lds_floats, skip_small, parts, row_amax); \
     } while (0)
     if (ch <= 1) BLGNN_GMN_LAUNCH(1);
     else if (ch == 2) BLGNN_GMN_LAUNCH(2);

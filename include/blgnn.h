@@ -268,10 +268,14 @@ int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                         const float *bn_shift, int32_t accumulate, void *stream);
 
 /* GMN message: model/layers_gmn.py:38-42 restructured:
- * y[i] = sum_{e: key_e = i} relu(p[i] + q[nbr_e])  (self loops kept). */
+ * y[i] = sum_{e: key_e = i} relu(p[i] + q[nbr_e])  (self loops kept).
+ * row_amax (optional, [n], initialised by the caller): row_amax[i] = max(row_amax[i], max_c y[i, c]) by atomic
+ * maximum -- one of the three producers of the f_node input's row magnitudes (blgnn_linear_h3), so that no
+ * pass over the [n, 4D] buffer is needed. */
 int blgnn_edge_relu_sum(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                         const float *p, int64_t ldp, const float *q, int64_t ldq,
-                        float *y, int64_t ldy, int32_t n, int32_t d, void *stream);
+                        float *y, int64_t ldy, int32_t n, int32_t d, float *row_amax,
+                        void *stream);
 /* row degree as float (for the deg_i * b2 term of the restructured message) */
 int blgnn_row_degree(const int32_t *rowptr, int32_t n, float *deg, void *stream);
 
@@ -351,9 +355,12 @@ int blgnn_linear_h3(const float *x, int64_t ldx, const float *row_amax, const vo
 
 /* model/layers_gmn.py:55-84.  Graphs (2k, 2k+1) of seg[] form pair k.
  * u[i] = x[i] - sum_j softmax_j(cos(x_i, x_j)) x_j, j over the partner graph.
- * seg has 2*num_pairs+1 entries. */
+ * seg has 2*num_pairs+1 entries.
+ * row_amax (optional, [rows], initialised by the caller): merged with max_c |u[i, c]| by atomic maximum
+ * (see blgnn_edge_relu_sum). */
 int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const float *x,
-                    int64_t ldx, float *u, int64_t ldu, int32_t d, void *stream);
+                    int64_t ldx, float *u, int64_t ldu, int32_t d, float *row_amax,
+                    void *stream);
 
 /* ---- pair scorer front end ----------------------------------------------- */
 

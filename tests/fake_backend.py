@@ -139,12 +139,12 @@ def segment_reduce_multi(seg, xs, kind="mean", row_map=None, out=None):
     return _put(out, torch.cat([segment_reduce(seg, x, kind) for x in xs], dim=1))
 
 
-def gmn_match(seg, x, out=None):
+def gmn_match(seg, x, out=None, row_amax=None):
     s = seg.tolist()
     return _put(out, oracle.gmn_match(x, [(s[i], s[i + 1]) for i in range(len(s) - 1)]))
 
 
-def edge_relu_sum(csr, p, q, out=None):
+def edge_relu_sum(csr, p, q, out=None, row_amax=None):
     return _put(out, oracle.scatter_add(torch.relu(p[csr.key] + q[csr.nbr]), csr.key, p.shape[0]))
 
 

@@ -602,8 +602,13 @@ def test_gmn_match(device, d, sizes):
     x = torch.randn(int(off[-1]), d)
     ref = oracle.gmn_match(x.double(), ind)
     seg = torch.as_tensor(off, dtype=torch.int32, device=device)
-    got = ops.gmn_match(seg, x.to(device))
+    floor = torch.rand(int(off[-1]), device=device) * 0.5           # what another producer already put there
+    am = floor.clone()
+    got = ops.gmn_match(seg, x.to(device), row_amax=am)
     assert max_err(got, ref) < TOL
+    # row magnitudes merged by atomic maximum: exactly max(previous, max_c |u|), whichever kernel took the pair
+    assert torch.equal(am, torch.maximum(floor, got.abs().amax(dim=1)))
+    assert torch.equal(ops.gmn_match(seg, x.to(device)), got)      # and the result does not depend on asking for them
 
 
 def test_gmn_match_on_operands_beyond_4_gib(device):
@@ -642,7 +647,13 @@ def test_edge_relu_sum_matches_message(device):
     dv = lambda t: t.to(device)
     csr = ops.csr_from_edge_index(dv(ei), n)
     pq = ops.linear(dv(x), dv(wpq), dv(bpq))
-    h = ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:])
+    am = torch.full((n,), 0.25, device=device)
+    h = ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:], row_amax=am)
+    assert torch.equal(am, torch.clamp(h.amax(dim=1), min=0.25))      # merged row maxima (this width: fallback pass)
+    wide_p, wide_q = torch.randn(n, 512, device=device), torch.randn(n, 512, device=device)
+    am2 = torch.zeros(n, device=device)
+    h2 = ops.edge_relu_sum(csr, wide_p, wide_q, row_amax=am2)          # d4 = 128: the kernel's own epilogue
+    assert torch.equal(am2, h2.amax(dim=1)) and torch.equal(h2, ops.edge_relu_sum(csr, wide_p, wide_q))
     got = ops.linear(h, dv(w2.t().contiguous()), None, rowvec=ops.row_degree(csr), rowvec_w=dv(b2))
     assert max_err(got, ref) < TOL
 
