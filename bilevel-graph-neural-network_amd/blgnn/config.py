@@ -65,7 +65,7 @@ def make_flags(model="higher_level_gnn", dataset="drugbank", lower_level_gnn_typ
                lower_level_num_layers=None, higher_level_num_layers=3, batch_size=None,
                device="cuda:0", node_aggr=None, bn=True, gnn_normalize=False,
                gat_softmax_group="src", d_init=64, feature_transform="f16x3", multi_edge_node_model="gat",
-               fuse_readout=True):
+               fuse_readout=True, gmn_f_node="MLP"):
     """Reproduce the flag values and layer list of src/config.py for ``model``.
     Defaults are the reference's (config.py:96,126-131,180,237-238)."""
     if model not in MODELS:
@@ -98,7 +98,7 @@ def make_flags(model="higher_level_gnn", dataset="drugbank", lower_level_gnn_typ
     if lower:
         layers.append(_node_embedding(lower_level_gnn_type, D_lower, "relu", bn, gnn_normalize))
         if gmn:
-            gm = "GMNPropagator:input_dim=%d,output_dim=%d,act=relu,bn=%s,f_node=MLP" % (D_lower, D_lower, bn)
+            gm = "GMNPropagator:input_dim=%d,output_dim=%d,act=relu,bn=%s,f_node=%s" % (D_lower, D_lower, bn, gmn_f_node)
             layers.append(gm)
         for i in range(lower_level_num_layers - 1):
             act = "relu" if i != lower_level_num_layers - 2 else "identity"

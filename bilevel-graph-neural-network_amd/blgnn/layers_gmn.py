@@ -97,8 +97,6 @@ class GMNPropagator(nn.Module):
 
     def forward(self, ins, batch_data, model, edge_index=None):
         ops.require_device(ins, "ins")
-        if self.f_node_name != 'MLP':
-            raise NotImplementedError("f_node='GRU' is a non-default variant outside the hot path")
         x = ins
         merge = batch_data.merge_data['merge']
         if edge_index is not None and edge_index is not merge.edge_index:
@@ -106,6 +104,8 @@ class GMNPropagator(nn.Module):
         else:
             csr = merge.csr()
         n, D = x.shape
+        if self.f_node_name == 'GRU':
+            return self._forward_gru(x, csr, merge, model)
         if self.training and torch.is_grad_enabled():
             return self._forward_train(x, csr, merge, model)
         with torch.no_grad():
@@ -150,6 +150,29 @@ class GMNPropagator(nn.Module):
                 af = ops.row_absmax(f_in)
             hid = ops.linear(f_in, w1, b1, act=act, rowvec=ops.row_degree(csr), rowvec_w=rw, amax_out=hid_amax, row_amax=af)
             out = ops.linear(hid, self.f_node.weight_kn(1), self.f_node.layers[1].bias, row_amax=hid_amax)
+        model.store_layer_output(self, out)
+        return out
+
+    def _forward_gru(self, x, csr, merge, model):
+        """f_node='GRU' (model/layers_gmn.py:27-30,48-50; non-default): out = GRUCell(cat(m_sum, u_sum), x).  The
+        message sum and the attention as in the MLP variant, the two gate GEMMs through blgnn_linear, the gate
+        arithmetic in one kernel.  Forward only."""
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("blgnn: f_node='GRU' runs forward-only")
+        n, D = x.shape
+        cell = self.f_node
+        with torch.no_grad():
+            wpq, bpq, w2, b2 = self._message_weights()
+            pq = ops.linear(x, wpq, bpq)
+            s = ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:])
+            gin = torch.empty((n, 3 * D), dtype=torch.float32, device=x.device)            # [m_sum | u_sum]
+            ops.linear(s, w2, None, rowvec=ops.row_degree(csr), rowvec_w=b2, out=gin[:, :2 * D])
+            ops.gmn_match(merge.segments(), x, out=gin[:, 2 * D:])
+            w_ih = self._cache.get("w_ih", lambda w: w.t().contiguous(), cell.weight_ih)
+            w_hh = self._cache.get("w_hh", lambda w: w.t().contiguous(), cell.weight_hh)
+            gi = ops.linear(gin, w_ih, cell.bias_ih)
+            gh = ops.linear(x, w_hh, cell.bias_hh)
+            out = ops.gru_gates(gi, gh, x)
         model.store_layer_output(self, out)
         return out
 

@@ -784,3 +784,17 @@ def grad_weight(g, x):
     dw = torch.empty((O, I), dtype=torch.float32, device=g.device)
     call("blgnn_grad_weight", gp, ldg, xp, ldx, M, O, I, scratch.data_ptr(), dw.data_ptr(), _stream())
     return dw
+
+
+def gru_gates(gi, gh, h, out=None):
+    """torch.nn.GRUCell's gate arithmetic on the two [n, 3D] gate tables and the state h [n, D]."""
+    gip, ldgi = _mat(gi, "gi")
+    ghp, ldgh = _mat(gh, "gh")
+    hp, ldh = _mat(h, "h")
+    n, D = h.shape
+    if gi.shape != (n, 3 * D) or gh.shape != (n, 3 * D):
+        raise ValueError("blgnn: gru_gates expects [n, 3D] gate tables")
+    y = _out(out, n, D, h)
+    yp, ldy = _mat(y, "out")
+    call("blgnn_gru_gates", gip, ldgi, ghp, ldgh, hp, ldh, n, D, yp, ldy, _stream())
+    return y

@@ -1,0 +1,34 @@
+// GRU cell gates for GMNPropagator(f_node='GRU') (model/layers_gmn.py:27-30,48-50; torch.nn.GRUCell):
+//   gi = in W_ih^T + b_ih,  gh = h W_hh^T + b_hh   (two blgnn_linear calls, [n, 3D] each, gate order r | z | n)
+//   r = sigmoid(gi_r + gh_r),  z = sigmoid(gi_z + gh_z),  c = tanh(gi_n + r * gh_n),  h' = (1 - z) * c + z * h
+// One pass over the two gate tables and the state: HBM-bound, 28 D bytes per node.
+#include "common.hpp"
+
+namespace blgnn {
+
+__global__ void __launch_bounds__(256) k_gru_gates(const float *__restrict__ gi, int64_t ldgi, const float *__restrict__ gh,
+                                                   int64_t ldgh, const float *__restrict__ h, int64_t ldh, int n, int D,
+                                                   float *__restrict__ out, int64_t ldo) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n * D) return;
+    const int i = (int)(idx / D), c = (int)(idx % D);
+    const float *a = gi + (int64_t)i * ldgi, *b = gh + (int64_t)i * ldgh;
+    const float r = 1.f / (1.f + expf(-(a[c] + b[c])));
+    const float z = 1.f / (1.f + expf(-(a[D + c] + b[D + c])));
+    const float cand = tanhf(a[2 * D + c] + r * b[2 * D + c]);
+    out[(int64_t)i * ldo + c] = (1.f - z) * cand + z * h[(int64_t)i * ldh + c];
+}
+
+}  // namespace blgnn
+
+using namespace blgnn;
+
+extern "C" int blgnn_gru_gates(const float *gi, int64_t ldgi, const float *gh, int64_t ldgh, const float *h, int64_t ldh,
+                               int32_t n, int32_t D, float *out, int64_t ldo, void *stream) {
+    BLGNN_CHECK_ARG(n >= 0 && D > 0 && ldgi >= 3 * D && ldgh >= 3 * D && ldh >= D && ldo >= D, "gru_gates: bad sizes");
+    if (n == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(gi && gh && h && out, "gru_gates: null pointer");
+    hipLaunchKernelGGL(k_gru_gates, dim3((unsigned)(((int64_t)n * D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gi, ldgi,
+                       gh, ldgh, h, ldh, n, D, out, ldo);
+    return launch_status("gru_gates");
+}

@@ -362,6 +362,12 @@ int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const float *x,
                     int64_t ldx, float *u, int64_t ldu, int32_t d, float *row_amax,
                     void *stream);
 
+/* GMNPropagator(f_node='GRU'): the gate arithmetic of torch.nn.GRUCell (model/layers_gmn.py:27-30,48-50) on the two
+ * gate tables gi = in W_ih^T + b_ih, gh = h W_hh^T + b_hh ([n, 3D], gate order r | z | n; two blgnn_linear calls):
+ *   out = (1 - z) * tanh(gi_n + r * gh_n) + z * h,  r = sigmoid(gi_r + gh_r),  z = sigmoid(gi_z + gh_z). */
+int blgnn_gru_gates(const float *gi, int64_t ldgi, const float *gh, int64_t ldgh, const float *h,
+                    int64_t ldh, int32_t n, int32_t D, float *out, int64_t ldo, void *stream);
+
 /* ---- pair scorer front end ----------------------------------------------- */
 
 /* out[b] = [ z[ids1[b]] / max(|z[ids1[b]]|, eps) , z[ids2[b]] / max(...) ]

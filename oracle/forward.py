@@ -133,10 +133,15 @@ def run_layers(specs, sd, plain, flags, first=0, x0=None):
         if name == "NodeEmbedding":
             out = _node_embedding(x, info, sd, p, plain, flags)
         elif name == "GMNPropagator":
-            out = ops.gmn_propagator(
-                x, plain["edge_index"], plain["ind_list"],
-                _mlp_params(sd, p + ".f_messasge")[0],
-                *_mlp_params(sd, p + ".f_node"), train=bool(flags.get("train")))
+            if info.get("f_node") == "GRU":
+                gru = tuple(sd[p + ".f_node." + k] for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+                out = ops.gmn_propagator(x, plain["edge_index"], plain["ind_list"],
+                                         _mlp_params(sd, p + ".f_messasge")[0], None, None, gru=gru)
+            else:
+                out = ops.gmn_propagator(
+                    x, plain["edge_index"], plain["ind_list"],
+                    _mlp_params(sd, p + ".f_messasge")[0],
+                    *_mlp_params(sd, p + ".f_node"), train=bool(flags.get("train")))
         elif name in ("NodeAggregation", "NodeAggregationPairs"):
             out = _aggregation(x, info, sd, p, plain, flags, acts)
         elif name == "LoadInteractionLayer":

@@ -254,10 +254,23 @@ def gmn_message_sum(x, edge_index, msg_linears):
     return scatter_add(m, row, x.shape[0])
 
 
-def gmn_propagator(x, edge_index, ind_list, msg_linears, node_linears, node_bns, train=False):
-    """model/layers_gmn.py:34-53 with f_node='MLP' (bn=True)."""
+def gru_cell(inp, h, w_ih, w_hh, b_ih, b_hh):
+    """torch.nn.GRUCell restated: gate order r | z | n."""
+    gi = inp @ w_ih.t() + b_ih
+    gh = h @ w_hh.t() + b_hh
+    D = h.shape[1]
+    r = torch.sigmoid(gi[:, :D] + gh[:, :D])
+    z = torch.sigmoid(gi[:, D:2 * D] + gh[:, D:2 * D])
+    c = torch.tanh(gi[:, 2 * D:] + r * gh[:, 2 * D:])
+    return (1 - z) * c + z * h
+
+
+def gmn_propagator(x, edge_index, ind_list, msg_linears, node_linears, node_bns, train=False, gru=None):
+    """model/layers_gmn.py:34-53: f_node='MLP' (bn=True), or 'GRU' when ``gru`` = (w_ih, w_hh, b_ih, b_hh)."""
     m_sum = gmn_message_sum(x, edge_index, msg_linears)
     u_sum = gmn_match(x, ind_list)
+    if gru is not None:
+        return gru_cell(torch.cat((m_sum, u_sum), dim=1), x, *gru)
     return mlp(torch.cat((x, m_sum, u_sum), dim=1), node_linears, "relu", node_bns, train=train)
 
 

@@ -143,6 +143,27 @@ def test_mhcaddi_gmn_forward(device):
         assert max_err(got, ref) < TOL
 
 
+def test_gmn_gru_node_update_forward(device):
+    """GMNPropagator(f_node='GRU') (model/layers_gmn.py:27-30,48-50, non-default): GRUCell(cat(m_sum, u_sum), x)"""
+    ds = blgnn.make_synthetic(40, 200, seed=6, device=device)
+    flags = blgnn.make_flags("lower_level_gmn", lower_level_gnn_type="gin", D_lower=64, device=device, gmn_f_node="GRU")
+    model, data = build(flags, ds, seed=9)
+    assert isinstance(model.layers[1].f_node, torch.nn.GRUCell)
+    specs = layer_specs(flags)
+    pairs = _pairs(ds, 16)
+    bd = blgnn.BatchData(pairs, ds, is_train=False, unique_graphs=False)
+    ids = torch.arange(2 * len(pairs)).reshape(-1, 2)
+    of = oracle_flags(flags, ds)
+    sd32 = calibrate_bn(model, specs, plain_batch(bd, ds, torch.float32, with_pairs=ids), of)
+    sd = {n: (v.double() if v.is_floating_point() else v) for n, v in sd32.items()}
+    acts = oracle.run_layers(specs, sd, plain_batch(bd, ds, torch.float64, with_pairs=ids), of)
+    model.acts = [bd.merge_data['merge'].x]
+    for layer in model.layers[:-1]:
+        model.acts.append(layer(model.acts[-1], bd, model))
+    for got, ref in zip(model.acts[1:], acts[1:]):
+        assert max_err(got, ref) < TOL
+
+
 @pytest.mark.parametrize("node_model", ["gat", "gcn"])
 def test_drugcombo_meta_forward(device, node_model):
     ds = blgnn.make_synthetic(70, 500, seed=8, device=device, num_edge_types=2, name="drugcombo_syn")
