@@ -62,6 +62,7 @@ SIGNATURES = {
     "blgnn_pack_weight_h3g": [_p, _i64, _i32, _i32, _p, _p],
     "blgnn_row_absmax": [_p, _i64, _i32, _i32, _p, _p],
     "blgnn_linear_h3": [_p, _i64, _p, _p, _p, _i64, _p, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p, _p],
+    "blgnn_hadamard": [_p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p],
     "blgnn_gru_gates": [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p],
     "blgnn_gmn_match": [_p, _i32, _p, _i64, _p, _i64, _i32, _p, _p],
     "blgnn_pair_gather_normalize": [_p, _i64, _p, _p, _i32, _i32, _f32, _p, _i64, _p],

@@ -186,6 +186,6 @@ class GMNAggregatorPairs(nn.Module):
 
     def forward(self, x, seg, out=None):
         weighted_x = self.weight_func(x)
-        gated_x = torch.sigmoid(self.gate_func(x))      # elementwise glue; non-default style
-        graph_embeddings = ops.segment_reduce(seg, gated_x * weighted_x, "sum")
+        gated_x = self.gate_func(x, final_act="sigmoid")                # the sigmoid rides on the last GEMM's epilogue
+        graph_embeddings = ops.segment_reduce(seg, ops.hadamard(gated_x, weighted_x), "sum")
         return self.mlp_graph(graph_embeddings, out=out)

@@ -798,3 +798,14 @@ def gru_gates(gi, gh, h, out=None):
     yp, ldy = _mat(y, "out")
     call("blgnn_gru_gates", gip, ldgi, ghp, ldgh, hp, ldh, n, D, yp, ldy, _stream())
     return y
+
+
+def hadamard(a, b, out=None):
+    ap, lda = _mat(a, "a")
+    bp, ldb = _mat(b, "b")
+    if a.shape != b.shape:
+        raise ValueError("blgnn: hadamard operands differ in shape")
+    y = _out(out, a.shape[0], a.shape[1], a)
+    yp, ldy = _mat(y, "out")
+    call("blgnn_hadamard", ap, lda, bp, ldb, a.shape[0], a.shape[1], yp, ldy, _stream())
+    return y

@@ -19,9 +19,28 @@ __global__ void __launch_bounds__(256) k_gru_gates(const float *__restrict__ gi,
     out[(int64_t)i * ldo + c] = (1.f - z) * cand + z * h[(int64_t)i * ldh + c];
 }
 
+// out = a * b elementwise (the gate of GMNAggregatorPairs: model/layers_aggregation.py:88-93)
+__global__ void __launch_bounds__(256) k_hadamard(const float *__restrict__ a, int64_t lda, const float *__restrict__ b, int64_t ldb,
+                                                  int n, int d, float *__restrict__ out, int64_t ldo) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n * d) return;
+    const int i = (int)(idx / d), c = (int)(idx % d);
+    out[(int64_t)i * ldo + c] = a[(int64_t)i * lda + c] * b[(int64_t)i * ldb + c];
+}
+
 }  // namespace blgnn
 
 using namespace blgnn;
+
+extern "C" int blgnn_hadamard(const float *a, int64_t lda, const float *b, int64_t ldb, int32_t n, int32_t d, float *out,
+                              int64_t ldo, void *stream) {
+    BLGNN_CHECK_ARG(n >= 0 && d > 0 && lda >= d && ldb >= d && ldo >= d, "hadamard: bad sizes");
+    if (n == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(a && b && out, "hadamard: null pointer");
+    hipLaunchKernelGGL(k_hadamard, dim3((unsigned)(((int64_t)n * d + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, lda, b,
+                       ldb, n, d, out, ldo);
+    return launch_status("hadamard");
+}
 
 extern "C" int blgnn_gru_gates(const float *gi, int64_t ldgi, const float *gh, int64_t ldgh, const float *h, int64_t ldh,
                                int32_t n, int32_t D, float *out, int64_t ldo, void *stream) {

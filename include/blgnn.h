@@ -368,6 +368,11 @@ int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const float *x,
 int blgnn_gru_gates(const float *gi, int64_t ldgi, const float *gh, int64_t ldgh, const float *h,
                     int64_t ldh, int32_t n, int32_t D, float *out, int64_t ldo, void *stream);
 
+/* out = a * b elementwise: the gate of GMNAggregatorPairs (model/layers_aggregation.py:88-93: sigmoid(gate) * weight,
+ * the sigmoid rides on the producing blgnn_linear's epilogue). */
+int blgnn_hadamard(const float *a, int64_t lda, const float *b, int64_t ldb, int32_t n, int32_t d,
+                   float *out, int64_t ldo, void *stream);
+
 /* ---- pair scorer front end ----------------------------------------------- */
 
 /* out[b] = [ z[ids1[b]] / max(|z[ids1[b]]|, eps) , z[ids2[b]] / max(...) ]

@@ -178,6 +178,10 @@ def require_device(t, name="tensor"):
     return None
 
 
+def hadamard(a, b, out=None):
+    return _put(out, a * b)
+
+
 def col_reduce(a, mode="sum", b=None, mean=None, rstd=None, scale=1.0, out=None):
     if mode == "sum":
         v = a.sum(0)
@@ -211,7 +215,7 @@ NAMES = ["csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear", "li
          "gin_layer",
          "gin_layer_supported", "gin_layer_x6_supported", "gat_conv", "gcn_conv",
          "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum", "row_degree", "pair_gather_normalize", "link_pred_head",
-         "l2_normalize_rows", "scatter_rows", "require_device", "col_reduce", "bn_apply", "bn_backward"]
+         "l2_normalize_rows", "scatter_rows", "require_device", "col_reduce", "bn_apply", "bn_backward", "hadamard"]
 
 
 def install(monkeypatch):
