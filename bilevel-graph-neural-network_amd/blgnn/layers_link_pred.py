@@ -95,7 +95,10 @@ class LinkPred(nn.Module):
                 pair_preds = self.mlp_concat(
                     cat, final_act="identity" if self.multi_label_pred else "sigmoid")
             else:
+                # 'dot_product' (non-default): sigmoid(<z1, z2>) as product kernel + a [d, 1] GEMM of ones with the
+                # sigmoid on its epilogue
                 d = ins.shape[1]
-                pair_preds = torch.sigmoid((cat[:, :d] * cat[:, d:]).sum(dim=1))
+                ones = torch.ones((d, 1), dtype=torch.float32, device=ins.device)
+                pair_preds = ops.linear(ops.hadamard(cat[:, :d], cat[:, d:]), ones, act="sigmoid", transform="f32").view(-1)
         batch_data.pair_preds = pair_preds
         return pair_preds

@@ -692,6 +692,20 @@ def test_link_pred_head_fused(device, d, dims, final):
     assert got.shape == ref.shape and max_err(got, ref) < TOL
 
 
+def test_link_pred_dot_product_module(device):
+    """LinkPred(type='dot_product') (model/layers_link_pred.py, non-default): sigmoid(<normalised z1, normalised z2>)"""
+    import types
+    from blgnn.layers_link_pred import LinkPred
+    g = torch.Generator().manual_seed(4)
+    z = torch.randn(90, 96, generator=g)
+    ids = torch.randint(0, 90, (300, 2), generator=g)
+    ref = oracle.link_pred(z.double(), ids[:, 0], ids[:, 1], None, "dot_product")
+    lp = LinkPred("dot_product", 96, 1)
+    bd = types.SimpleNamespace(_pair_row_ids=(ids[:, 0].contiguous().to(device), ids[:, 1].contiguous().to(device)))
+    got = lp(z.to(device), bd, None)
+    assert max_err(got.view(-1), ref.view(-1)) < TOL
+
+
 def test_errors_are_loud(device):
     with pytest.raises(RuntimeError):
         ops.linear(torch.randn(4, 4), torch.randn(4, 4))          # CPU tensors: no fallback
