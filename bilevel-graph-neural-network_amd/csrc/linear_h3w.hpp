@@ -15,6 +15,9 @@
 // Measured (462 k rows): K = N = 1024 3.47 ms (was 3.70-3.78), K = 256 / N = 1024 1.29 (1.46), K = 1024 / N = 256 1.16
 // (1.21).  Letting the feeders carry the second W piece through registers (the LDS-DMA path then moves half) changed
 // nothing: 3.53 ms.
+// A persistent variant (one workgroup per CU walking tiles, stages rotating so that the feeders park step 0 of the next
+// tile and its first W image flies while the MFMA waves run the epilogue) measured 1.26 vs 1.33 ms at K = 256 but 3.76 vs
+// 3.63 ms at K = 1024 and 1.23 vs 1.19 at K = 1024 / N = 256 (static tile assignment, store drain at the tile start): dropped.
 // LDS rows are 64 B (32 fp16); the 16-byte chunk index is XORed with (row >> 2) & 3, so the 16 lanes a ds_read_b128
 // serves together (rows r .. r + 15, one chunk index) cover all 16 chunk slots of four consecutive rows' 256 bytes.
 #pragma once
