@@ -101,6 +101,8 @@ def parse():
     ap.add_argument("--gmn-fused-amax", action="store_true",
                     help="GMN configs: the producers of the f_node input merge its row magnitudes (atomic maximum) instead "
                          "of a pass over it (measured: no gain)")
+    ap.add_argument("--no-gmn-sp", action="store_true",
+                    help="GMN configs: the in-kernel operand split of blgnn_linear_h3 instead of the pre-split pipeline")
     ap.add_argument("--gmn-streams", type=int, default=1,
                     help="GMN configs: consecutive steps (independent pair batches) alternate over this many streams")
     ap.add_argument("--no-fuse-readout", action="store_true",
@@ -228,7 +230,7 @@ def perturb_bn(model, seed):
 def pmc_traffic(tag):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
     (profiles/summarize_pmc.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction), or None."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.json" % (rnd, tag))))[
                 "hbm_bytes_per_launch"]
@@ -574,6 +576,7 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
     flags = blgnn.make_flags("lower_level_gmn", dataset=cfg["dataset"], lower_level_gnn_type="gin", D_lower=d,
                              device=device, batch_size=batch, feature_transform=transform)
     flags.gmn_fused_amax = bool(getattr(args, "gmn_fused_amax", False))
+    flags.gmn_sp = not getattr(args, "no_gmn_sp", False)
     blgnn.set_flags(flags)
     torch.manual_seed(seed)
     data = blgnn.TrainData(ds, device=device, num_hyper_edge_feat=3 if cfg["edge_types"] > 1 else 0)
@@ -606,6 +609,9 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
         N = w_kn.shape[1]
         return (2.0 * M * N * K, 4.0 * M * (K + N) + 4.0 * K * N)
     ops.linear = timer.wrap(transform, saved, lin_work, lambda x, w_kn, *a, **kw: x.shape[0] >= min_rows)
+    # the pre-split pipeline (default at these sizes): same products, operands in the sp format (4 B per element too)
+    saved_sp = ops.linear_sp
+    ops.linear_sp = timer.wrap("sp", saved_sp, lin_work, lambda x, w_kn, *a, **kw: x.shape[0] >= min_rows)
     import blgnn.layers_gmn as _lg
     import blgnn.layers_util as _lu
     assert _lg.ops is ops and _lu.ops is ops               # the modules call ops.linear through the module
@@ -644,6 +650,7 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
             timer.enabled = False
     finally:
         ops.linear = saved
+        ops.linear_sp = saved_sp
     pairs_per_step = batch * world
     res = {"value": pairs_per_step / (elapsed / steps), "ms_per_step": 1e3 * elapsed / steps,
            "timed_blocks": len(blocks), "ms_per_step_min": 1e3 * min(blocks) / steps,
@@ -662,6 +669,11 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
                            "products per fp32 product, act/BN epilogue)",
                  "f32": "k_linear (f_message / f_node GEMMs of the GMN propagator, exact-f32 MFMA)"}[transform]
         tag = {"f16x3": "linear_h3", "bf16x6": "linear_x6", "f32": "linear"}[transform]
+        if names and all(nm == "sp" for nm in names):
+            kname = ("k_linear_sp (f_message / f_node GEMMs of the GMN propagator over all atoms on PRE-SPLIT operands: "
+                     "3 fp16 MFMA products per fp32 product, 256 x 256 tiles, both operands by LDS-DMA, block-scaled "
+                     "fp16 piece planes written by the producers' epilogues, act/BN epilogue)")
+            tag = "linear_sp"
         res["roofline"] = roofline_of(kname, ms, work, mult, peak, pmc_traffic(tag + "_cfg%d" % cfg_id))
     res["_cpu"] = lambda seconds: cpu_baseline_gmn(ds, flags, model, batch, seconds, seed)
     return res

@@ -37,7 +37,7 @@ SIGNATURES = {
     "blgnn_pack_weight_x6": [_p, _i64, _i32, _i32, _p, _p],
     "blgnn_pack_weight_h3": [_p, _i64, _i32, _i32, _p, _p],
     "blgnn_gin_layer_h3": [_p, _p, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _p, _i32, _f32, _i32, _p, _p, _p,
-                           _p, _i64, _p, _p, _p, _i64, _i32, _p, _p],
+                           _p, _i64, _p, _p, _p, _i64, _i32, _p, _p, _i64, _p, _i64, _p],
     "blgnn_gin_layer_h3_codes": [_p, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p, _p, _i32, _f32, _i32, _p, _p, _p,
                                  _p, _i64, _p, _p, _p, _i64, _i32, _p, _p],
     "blgnn_gin_layer_x6": [_p, _p, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _p, _i32, _f32, _i32, _p, _p, _p,
@@ -52,7 +52,7 @@ SIGNATURES = {
     "blgnn_gat_softmax_stats": [_p, _p, _i64, _p, _p, _i32, _i32, _f32, _p, _p, _p],
     "blgnn_gat_aggregate": [_p, _p, _i64, _p, _i64, _p, _p, _p, _p, _i32, _f32, _p, _i64, _i32, _i32,
                             _p, _i32, _p, _p, _p, _i32, _p],
-    "blgnn_edge_relu_sum": [_p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _p],
+    "blgnn_edge_relu_sum": [_p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _p, _i64, _p, _i64, _p],
     "blgnn_row_degree": [_p, _i32, _p, _p],
     "blgnn_segment_reduce": [_p, _i32, _p, _i64, _i32, _i32, _p, _i64, _p, _p],
     "blgnn_segment_reduce_multi": [_p, _i32, _i32, _p, _p, _p, _i32, _p, _i64, _p, _p],
@@ -62,6 +62,11 @@ SIGNATURES = {
     "blgnn_pack_weight_h3g": [_p, _i64, _i32, _i32, _p, _p],
     "blgnn_row_absmax": [_p, _i64, _i32, _i32, _p, _p],
     "blgnn_linear_h3": [_p, _i64, _p, _p, _p, _i64, _p, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p, _p],
+    "blgnn_pack_weight_sp": [_p, _i64, _i32, _i32, _p, _p],
+    "blgnn_split_rows_sp": [_p, _i64, _i32, _i32, _p, _i64, _p, _i64, _p],
+    "blgnn_join_rows_sp": [_p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p],
+    "blgnn_linear_sp": [_p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _i32, _p,
+                        _p, _p, _p],
     "blgnn_hadamard": [_p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p],
     "blgnn_gru_gates": [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p],
     "blgnn_gmn_match": [_p, _i32, _p, _i64, _p, _i64, _i32, _p, _p],
@@ -86,7 +91,7 @@ SIGNATURES = {
     "blgnn_gat_backward_features": [_p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _p, _i64, _p],
 }
 LIBRARY_SYMBOLS = ["blgnn_version", "blgnn_last_error", "blgnn_device_count", "blgnn_packed_weight_x6_elems",
-                   "blgnn_packed_weight_h3_elems", "blgnn_packed_weight_h3g_elems",
+                   "blgnn_packed_weight_h3_elems", "blgnn_packed_weight_h3g_elems", "blgnn_packed_weight_sp_elems",
                    "blgnn_col_reduce_scratch_elems", "blgnn_grad_weight_scratch_elems"]
 
 _lib = None
@@ -120,6 +125,8 @@ def load():
     lib.blgnn_packed_weight_h3_elems.restype = ctypes.c_int64
     lib.blgnn_packed_weight_h3g_elems.argtypes = [_i32, _i32]
     lib.blgnn_packed_weight_h3g_elems.restype = ctypes.c_int64
+    lib.blgnn_packed_weight_sp_elems.argtypes = [_i32, _i32]
+    lib.blgnn_packed_weight_sp_elems.restype = ctypes.c_int64
     lib.blgnn_col_reduce_scratch_elems.argtypes = [_i32, _i32]
     lib.blgnn_col_reduce_scratch_elems.restype = ctypes.c_int64
     lib.blgnn_grad_weight_scratch_elems.argtypes = [_i32, _i32, _i32]

@@ -65,7 +65,7 @@ def make_flags(model="higher_level_gnn", dataset="drugbank", lower_level_gnn_typ
                lower_level_num_layers=None, higher_level_num_layers=3, batch_size=None,
                device="cuda:0", node_aggr=None, bn=True, gnn_normalize=False,
                gat_softmax_group="src", d_init=64, feature_transform="f16x3", multi_edge_node_model="gat",
-               fuse_readout=True, gmn_f_node="MLP"):
+               fuse_readout=True, gmn_f_node="MLP", gmn_sp=True):
     """Reproduce the flag values and layer list of src/config.py for ``model``.
     Defaults are the reference's (config.py:96,126-131,180,237-238)."""
     if model not in MODELS:
@@ -159,6 +159,7 @@ def make_flags(model="higher_level_gnn", dataset="drugbank", lower_level_gnn_typ
     # node -> graph readout accumulated by the producing GIN layers' epilogues instead of a separate
     # segment-reduce launch (blgnn/layers.py ReadoutPlan; not a reference flag)
     f.fuse_readout = fuse_readout
+    f.gmn_sp = gmn_sp                                  # pre-split GEMM operands in the GMN propagator (layers_gmn.py)
     if last_lower is not None:
         f.last_lower_lyr_num = last_lower
     for i, s in enumerate(layers):

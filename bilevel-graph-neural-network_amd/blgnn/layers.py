@@ -178,12 +178,19 @@ class NodeEmbedding(nn.Module):
                 pool = plan.pool_for(self) if plan is not None else None
             fused_pool = False
             wide = None
+            want_sp = False
             if self.type == 'gin' and out is None and not self.higher_level and not self.normalize \
                     and 'gmn' in FLAGS.model:
                 # the GMNPropagator that follows reads this layer's output as the first D columns of its [n, 4D]
                 # f_node input (model/layers_gmn.py:44-46): produce it there instead of copying it later
-                wide = torch.empty((ins.shape[0], 4 * self.out_dim), dtype=torch.float32, device=ins.device)
-                out = wide[:, :self.out_dim]
+                from .layers_gmn import GMNPropagator
+                if GMNPropagator._use_sp(ins.shape[0], self.out_dim):
+                    # sp pipeline: the propagator's GEMMs read this layer's output as fp16 piece planes, written by
+                    # the layer kernel's store loop next to the fp32 rows (which the attention kernel reads)
+                    want_sp = True
+                else:
+                    wide = torch.empty((ins.shape[0], 4 * self.out_dim), dtype=torch.float32, device=ins.device)
+                    out = wide[:, :self.out_dim]
             if self.type == 'gin':
                 lin1, lin2 = self.conv.nn[0], self.conv.nn[2]
                 w1 = self._cache.get("w1", lambda w: w.t().contiguous(), lin1.weight)
@@ -210,11 +217,16 @@ class NodeEmbedding(nn.Module):
                     # (GMN models: the propagator's message GEMM normalises this output row by row; its row
                     # magnitudes come out of this kernel's store loop instead of a pass over the result)
                     amax = torch.empty(ins.shape[0], dtype=torch.float32, device=ins.device) if wide is not None else None
+                    f_sp = ops.SpRows(ins.shape[0], 4 * self.out_dim, ins.device) \
+                        if (want_sp and self.out_dim == ops.SpRows.BLOCK) else None
+                    sp_x = f_sp.cols(0, self.out_dim) if f_sp is not None else None
                     x = ops.gin_layer_h3(csr, ins, w1p, lin1.bias, w2p, lin2.bias, self.out_dim, eps=eps,
                                          act=act, act_param=slopes, bn_scale=scale, bn_shift=shift, out=out, pool=pool,
-                                         amax_out=amax)
+                                         amax_out=amax, out_sp=sp_x)
                     if amax is not None:
                         x._blgnn_amax = amax
+                    if sp_x is not None:
+                        x._blgnn_sp = f_sp
                     fused_pool = True
                 elif transform in ("bf16x6", "f16x3") and \
                         ops.gin_layer_x6_supported(csr, ins, ins.shape[1], self.out_dim):

@@ -108,6 +108,8 @@ class GMNPropagator(nn.Module):
             return self._forward_gru(x, csr, merge, model)
         if self.training and torch.is_grad_enabled():
             return self._forward_train(x, csr, merge, model)
+        if self._use_sp(n, D):
+            return self._forward_sp(x, csr, merge, model)
         with torch.no_grad():
             wpq, bpq, _, _ = self._message_weights()
             w1, b1, rw = self._node_weights()
@@ -150,6 +152,57 @@ class GMNPropagator(nn.Module):
                 af = ops.row_absmax(f_in)
             hid = ops.linear(f_in, w1, b1, act=act, rowvec=ops.row_degree(csr), rowvec_w=rw, amax_out=hid_amax, row_amax=af)
             out = ops.linear(hid, self.f_node.weight_kn(1), self.f_node.layers[1].bias, row_amax=hid_amax)
+        model.store_layer_output(self, out)
+        return out
+
+    @staticmethod
+    def _use_sp(n, D):
+        """The pre-split ("sp") pipeline: FLAGS.gmn_sp = True (default: when the GEMMs are large enough for the
+        256 x 256 tiles), "force" (any size: tests) or False (the in-kernel split of blgnn_linear_h3)."""
+        mode = getattr(FLAGS, "gmn_sp", True)
+        if not mode or getattr(FLAGS, "feature_transform", "f16x3") != "f16x3" or D % ops.SpRows.BLOCK != 0 or 4 * D > 2048:
+            return False
+        return mode == "force" or ops.linear_sp_supported(n, D, 4 * D)
+
+    def _forward_sp(self, x, csr, merge, model):
+        """Eval forward with every GEMM operand in the sp format (include/blgnn.h: blgnn_linear_sp): each producer
+        splits its result ONCE into two fp16 piece planes with a power-of-two scale per (row, 256 columns) -- the
+        GIN layer x (its store loop), the edge kernel S, f_node's first Linear the hidden layer (GEMM epilogue); the
+        attention's u by one streaming pass on its side stream -- and the three GEMMs stream both operands by LDS-DMA
+        with all eight waves on the matrix cores.  Same arithmetic as ``forward``'s default path (three fp16 MFMA
+        products per fp32 product); no row-magnitude passes, no [n, 4D] fp32 f_node input."""
+        n, D = x.shape
+        with torch.no_grad():
+            wpq, bpq, _, _ = self._message_weights()
+            w1, b1, rw = self._node_weights()
+            f_sp = getattr(x, "_blgnn_sp", None)                 # the producing GIN layer wrote x's planes there
+            if f_sp is None or tuple(f_sp.shape) != (n, 4 * D):
+                f_sp = ops.SpRows(n, 4 * D, x.device)
+                ops.split_rows_sp(x, out=f_sp.cols(0, D))
+            side = self._side_stream(x.device) if (x.is_cuda and getattr(FLAGS, "gmn_overlap_match", True)) else None
+            seg = merge.segments()                               # (built on the launch stream, before the fork)
+
+            def match():
+                u = ops.gmn_match(seg, x)
+                ops.split_rows_sp(u, out=f_sp.cols(3 * D, 4 * D))
+                return u
+
+            if side is not None:
+                cur = torch.cuda.current_stream(x.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    u = match()
+                    u.record_stream(side)
+            pq, _ = ops.linear_sp(f_sp.cols(0, D), wpq, bpq)                              # [n, 4D] = [P | Q], fp32
+            ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:], out_sp=f_sp.cols(D, 3 * D))
+            if side is not None:
+                cur.wait_stream(side)
+            else:
+                match()
+            hid = ops.SpRows(n, 4 * D, x.device)
+            ops.linear_sp(f_sp, w1, b1, act=act_name(self.f_node.activation), rowvec=ops.row_degree(csr), rowvec_w=rw,
+                          out_sp=hid)
+            out, _ = ops.linear_sp(hid, self.f_node.weight_kn(1), self.f_node.layers[1].bias)
         model.store_layer_output(self, out)
         return out
 

@@ -197,10 +197,11 @@ def _pool_args(pool, n, N):
 
 
 def gin_layer_h3(csr, x, w1_packed, b1, w2_packed, b2, N, eps=0.0, act="identity", act_param=None,
-                 bn_scale=None, bn_shift=None, out=None, pool=None, amax_out=None):
+                 bn_scale=None, bn_shift=None, out=None, pool=None, amax_out=None, out_sp=None):
     """blgnn_gin_layer with both GEMMs on the fp16 matrix cores at fp32 accuracy (f16x3).  ``pool``: fused
     node -> graph readout of the result into a zero-initialised [G, N] view (see ``_pool_args``).  ``amax_out``
-    [n]: receives the row magnitudes of the result (for a following f16x3 GEMM)."""
+    [n]: receives the row magnitudes of the result (for a following f16x3 GEMM).  ``out_sp`` (``SpRows`` [n, 256],
+    N == 256): the result additionally in the sp format ``linear_sp`` reads."""
     xp, ldx = _mat(x, "x")
     n, K = x.shape
     y = _out(out, n, N, x)
@@ -208,7 +209,7 @@ def gin_layer_h3(csr, x, w1_packed, b1, w2_packed, b2, N, eps=0.0, act="identity
     call("blgnn_gin_layer_h3", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, xp, ldx, n, K,
          w1_packed.data_ptr(), _vec(b1, "b1"), w2_packed.data_ptr(), _vec(b2, "b2"), N, float(eps), _act(act),
          _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), yp, ldy,
-         *_pool_args(pool, n, N), _vec(amax_out, "amax_out"), _stream())
+         *_pool_args(pool, n, N), _vec(amax_out, "amax_out"), *_sp_args(out_sp, n, N), _stream())
     return y
 
 
@@ -329,9 +330,108 @@ def _packed_weight(w_kn, kind="x6"):
     if len(_PACKED) > 512:
         for k in [k for k, v in _PACKED.items() if v[0]() is None]:
             del _PACKED[k]
-    packed = pack_weight_h3g(w_kn) if kind == "h3g" else pack_weight_x6(w_kn)
+    packed = pack_weight_h3g(w_kn) if kind == "h3g" else pack_weight_sp(w_kn) if kind == "sp" else pack_weight_x6(w_kn)
     _PACKED[key] = (weakref.ref(w_kn), stamp, packed)
     return packed
+
+
+class SpRows:
+    """An activation matrix [rows, cols] in the sp format of ``blgnn_linear_sp`` (include/blgnn.h, csrc/sp_common.hpp):
+    ``planes`` fp16 [rows, 2 * cols] (per 32-column chunk: 32 high pieces, then 32 low pieces) and ``scales`` fp32
+    [rows, cols / 256] (inverse power-of-two scale of every 256-column block) -- the same bytes as fp32, split once
+    by the producer.  ``cols(c0, c1)`` (multiples of 256) is a view: producers fill their slices independently."""
+
+    BLOCK = 256
+
+    def __init__(self, rows=None, cols=None, device=None, planes=None, scales=None):
+        if planes is None:
+            if cols % self.BLOCK != 0:
+                raise ValueError("blgnn: sp matrices need a multiple of 256 columns (got %d)" % cols)
+            planes = torch.empty((rows, 2 * cols), dtype=torch.float16, device=device)
+            scales = torch.empty((rows, cols // self.BLOCK), dtype=torch.float32, device=device)
+        self.planes, self.scales = planes, scales
+
+    @property
+    def shape(self):
+        return (self.planes.shape[0], self.planes.shape[1] // 2)
+
+    @property
+    def device(self):
+        return self.planes.device
+
+    def cols(self, c0, c1):
+        if c0 % self.BLOCK or c1 % self.BLOCK or not 0 <= c0 < c1 <= self.shape[1]:
+            raise ValueError("blgnn: sp column slices start and end on multiples of 256")
+        return SpRows(planes=self.planes[:, 2 * c0:2 * c1], scales=self.scales[:, c0 // self.BLOCK:c1 // self.BLOCK])
+
+
+def _sp_args(sp, rows, cols):
+    """-> (planes ptr, ld in fp16 elements, scales ptr, ld) for the C ABI; four nulls for None."""
+    if sp is None:
+        return None, 0, None, 0
+    if tuple(sp.shape) != (rows, cols):
+        raise ValueError("blgnn: sp matrix has shape %s, expected %s" % (tuple(sp.shape), (rows, cols)))
+    pl, sc = sp.planes, sp.scales
+    if pl.dtype != torch.float16 or sc.dtype != torch.float32 or pl.stride(1) != 1 or sc.stride(1) != 1:
+        raise ValueError("blgnn: sp planes must be fp16 rows, scales fp32 rows")
+    require_device(pl, "sp planes")
+    return pl.data_ptr(), pl.stride(0), sc.data_ptr(), sc.stride(0)
+
+
+def pack_weight_sp(w_kn):
+    """[K, N] fp32 weights (N % 256 == 0) -> the tile-ordered two-piece fp16 image ``linear_sp`` streams."""
+    wp, ldw = _mat(w_kn, "w")
+    K, N = w_kn.shape
+    if N % SpRows.BLOCK != 0 or N == 0 or K == 0:
+        raise ValueError("blgnn: the sp GEMM needs N %% 256 == 0 (got [%d, %d])" % (K, N))
+    out = torch.empty(int(_lib.load().blgnn_packed_weight_sp_elems(K, N)), dtype=torch.float16, device=w_kn.device)
+    call("blgnn_pack_weight_sp", wp, ldw, K, N, out.data_ptr(), _stream())
+    return out
+
+
+def split_rows_sp(x, out=None):
+    """fp32 rows -> sp format (one streaming pass; producers with an sp epilogue do not need it)."""
+    xp, ldx = _mat(x, "x")
+    M, K = x.shape
+    sp = out if out is not None else SpRows(M, K, x.device)
+    call("blgnn_split_rows_sp", xp, ldx, M, K, *_sp_args(sp, M, K), _stream())
+    return sp
+
+
+def join_rows_sp(sp, out=None):
+    """sp format -> fp32 rows."""
+    M, K = sp.shape
+    y = _out(out, M, K, sp.planes)
+    yp, ldy = _mat(y, "out")
+    call("blgnn_join_rows_sp", *_sp_args(sp, M, K), M, K, yp, ldy, _stream())
+    return y
+
+
+def linear_sp_supported(M, K, N):
+    """Shapes ``linear_sp`` is written for: whole 256-column blocks on both sides; below ~one tile per CU the
+    smaller-tile kernels win."""
+    return K % 256 == 0 and 0 < K <= 2048 and N % 256 == 0 and N > 0 and M >= 32768
+
+
+def linear_sp(xs, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn_shift=None,
+              rowvec=None, rowvec_w=None, out=None, out_sp=None, f32=None):
+    """epi(X @ w_kn + bias [+ rowvec (x) rowvec_w]) with X an ``SpRows``.  The result goes to fp32 rows (``out``, or a
+    new tensor when ``f32``; default: when no ``out_sp`` is given), to ``out_sp`` (``SpRows``), or to both.
+    -> (fp32 result or None, out_sp or None)."""
+    M, K = xs.shape
+    if w_kn.shape[0] != K:
+        raise ValueError("blgnn: x is [%d,%d] but w is [%d,%d]" % (M, K, w_kn.shape[0], w_kn.shape[1]))
+    N = w_kn.shape[1]
+    if f32 is None:
+        f32 = out_sp is None
+    y, yp, ldy = None, None, 0
+    if f32 or out is not None:
+        y = _out(out, M, N, xs.planes)
+        yp, ldy = _mat(y, "out")
+    call("blgnn_linear_sp", *_sp_args(xs, M, K), _packed_weight(w_kn, "sp").data_ptr(), yp, ldy,
+         *_sp_args(out_sp, M, N), M, N, K, _vec(bias, "bias"), _vec(rowvec, "rowvec"), _vec(rowvec_w, "rowvec_w"),
+         _act(act), _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), _stream())
+    return y, out_sp
 
 
 def linear_writes_amax(x, w_kn, transform=None):
@@ -548,15 +648,20 @@ def gmn_match(seg, x, out=None, row_amax=None):
     return u
 
 
-def edge_relu_sum(csr, p, q, out=None, row_amax=None):
-    """``row_amax`` [n]: merged with the row maxima of the result (atomic maximum)."""
+def edge_relu_sum(csr, p, q, out=None, row_amax=None, out_sp=None):
+    """``row_amax`` [n]: merged with the row maxima of the result (atomic maximum).  ``out_sp`` (``SpRows`` [n, d],
+    d % 256 == 0): the result goes there in the sp format INSTEAD of fp32 rows (returns ``out_sp``)."""
     pp, ldp = _mat(p, "p")
     qp, ldq = _mat(q, "q")
     n, d = p.shape
+    if out_sp is not None:
+        call("blgnn_edge_relu_sum", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, pp, ldp, qp, ldq, None,
+             0, n, d, None, *_sp_args(out_sp, n, d), _stream())
+        return out_sp
     y = _out(out, n, d, p)
     yp, ldy = _mat(y, "out")
     call("blgnn_edge_relu_sum", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, pp, ldp, qp, ldq, yp,
-         ldy, n, d, _vec(row_amax, "row_amax"), _stream())
+         ldy, n, d, _vec(row_amax, "row_amax"), None, 0, None, 0, _stream())
     return y
 
 

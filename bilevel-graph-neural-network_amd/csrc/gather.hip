@@ -15,6 +15,7 @@
 //   GAT : exp(lrelu(sd_i + ss_j) - mx_g)/(den_g+1e-16), appended self loop (GATConv)
 //   RELU: acc += relu(p_i + q_j)                  (restructured GMN message)
 #include "common.hpp"
+#include "sp_common.hpp"
 
 namespace blgnn {
 
@@ -41,6 +42,10 @@ struct GatherArgs {
     const float *p;
     int64_t ldp;
     float *amax;         // optional [n]: atomic max of the result row's magnitudes into it (k_gather only)
+    _Float16 *ys;        // optional sp-format output (sp_common.hpp; k_gather with one wavefront per row, d % 256 == 0);
+    int64_t ldys;        //   y itself may then be null
+    float *ye;
+    int64_t ldye;
     // epilogue
     Epilogue epi;
     int32_t accumulate;
@@ -160,6 +165,23 @@ __global__ void __launch_bounds__(256) k_gather(const GatherArgs A) {
                     }
                 }
             }
+        }
+        if (MODE == MODE_RELU && LG == 64 && A.ys) {
+            // sp output: chunk k of the row is exactly its k-th 256-column scale block, held by the 64 lanes of
+            // this wavefront -- block maximum (sums of relus are non-negative), power-of-two scale, two fp16 pieces
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                if (!ok[k]) continue;                                  // wave-uniform (d4 is a multiple of 64)
+                float mx = fmaxf(fmaxf(acc[k].x, acc[k].y), fmaxf(acc[k].z, acc[k].w));
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, WAVE));
+                float sc, inv;
+                pow2_scale(mx, sc, inv);
+                if (l == 0) A.ye[(int64_t)row * A.ldye + k] = inv;
+                const f32x4v sv = {acc[k].x * sc, acc[k].y * sc, acc[k].z * sc, acc[k].w * sc};
+                sp_store4(A.ys + (int64_t)row * A.ldys + k * (2 * SP_BLOCK), 4 * l, sv);
+            }
+            if (!A.y) continue;
         }
         float4 *Y = reinterpret_cast<float4 *>(A.y) + (int64_t)row * ldy4;
         if (MODE == MODE_RELU && A.amax) {
@@ -907,16 +929,35 @@ extern "C" int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col, in
 
 extern "C" int blgnn_edge_relu_sum(const int32_t *rowptr, const int32_t *col, int64_t nnz, const float *p,
                                    int64_t ldp, const float *q, int64_t ldq, float *y,
-                                   int64_t ldy, int32_t n, int32_t d, float *row_amax, void *stream) {
+                                   int64_t ldy, int32_t n, int32_t d, float *row_amax, void *y_sp, int64_t ld_ysp,
+                                   float *y_spe, int64_t ld_yspe, void *stream) {
     if (int rc = check_csr(rowptr, col, n, nnz, "edge_relu_sum")) return rc;
-    BLGNN_CHECK_ARG(d >= 0 && (n == 0 || d == 0 || (p && q && y)), "edge_relu_sum: null pointer");
-    BLGNN_CHECK_ARG(ldp >= d && ldq >= d && ldy >= d, "edge_relu_sum: leading dimension < d");
+    BLGNN_CHECK_ARG(d >= 0 && (n == 0 || d == 0 || (p && q && (y || y_sp))), "edge_relu_sum: null pointer");
+    BLGNN_CHECK_ARG(ldp >= d && ldq >= d && (!y || ldy >= d), "edge_relu_sum: leading dimension < d");
     BLGNN_CHECK_ARG(y != p && y != q, "edge_relu_sum: output must not alias inputs");
     GatherArgs A = {};
-    A.rowptr = rowptr; A.col = col; A.x = q; A.ldx = ldq; A.y = y; A.ldy = ldy; A.n = n; A.d = d;
+    A.rowptr = rowptr; A.col = col; A.x = q; A.ldx = ldq; A.y = y; A.ldy = y ? ldy : d; A.n = n; A.d = d;
     A.p = p; A.ldp = ldp;
     A.amax = row_amax;
     const bool pa = (ldp % 4 == 0) && aligned16(p);
+    if (y_sp) {
+        // the sp epilogue lives in the one-wavefront-per-row kernel (a chunk of 64 lanes x 4 columns = one scale block)
+        BLGNN_CHECK_ARG(y_spe && ld_ysp >= 2 * (int64_t)d && ld_ysp % 8 == 0 && aligned16(y_sp) && ld_yspe >= d / SP_BLOCK,
+                        "edge_relu_sum: bad sp output planes");
+        if (d % SP_BLOCK != 0 || d > 2048 || !pa || ldq % 4 != 0 || !aligned16(q) || (y && (ldy % 4 != 0 || !aligned16(y))))
+            return fail(BLGNN_ERR_UNSUPPORTED, "edge_relu_sum: sp output needs d %% 256 == 0, d <= 2048 and 16-byte aligned rows (d=%d)", d);
+        if (n == 0 || d == 0) return BLGNN_OK;
+        A.ys = reinterpret_cast<_Float16 *>(y_sp); A.ldys = ld_ysp; A.ye = y_spe; A.ldye = ld_yspe;
+        hipStream_t s = (hipStream_t)stream;
+        const int d4 = d / 4;
+        if (d4 <= 64) launch_vec<MODE_RELU, 64, 1>(A, s);
+        else if (d4 <= 128) launch_vec<MODE_RELU, 64, 2>(A, s);
+        else if (d4 <= 192) launch_vec<MODE_RELU, 64, 3>(A, s);
+        else if (d4 <= 256) launch_vec<MODE_RELU, 64, 4>(A, s);
+        else if (d4 <= 320) launch_vec<MODE_RELU, 64, 5>(A, s);
+        else launch_vec<MODE_RELU, 64, 8>(A, s);
+        return launch_status("edge_relu_sum");
+    }
     bool native = false;
     const int rc = dispatch<MODE_RELU>(A, nnz, pa, (hipStream_t)stream, "edge_relu_sum", &native);
     if (rc != BLGNN_OK || !row_amax || native || n == 0 || d == 0) return rc;

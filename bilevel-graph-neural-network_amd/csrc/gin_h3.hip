@@ -21,6 +21,7 @@
 // four consecutive output columns of one row.
 #include "gin_common.hpp"
 #include "h3_common.hpp"
+#include "sp_common.hpp"
 
 namespace blgnn {
 
@@ -76,6 +77,8 @@ struct GinH3Args {
     float *pool; int64_t ldp;                // zero-initialised by the caller; nullptr = no readout
     int32_t pool_mean;                       // w = 1 / max(rows of the graph, 1), else 1
     float *y_amax;                           // optional [n]: max |y[i, :]| per row (row scale of a following f16x3 GEMM)
+    _Float16 *ysp; int64_t ldysp;            // optional (N == 256): y also in the sp format (sp_common.hpp) ...
+    float *yspe; int64_t ldyspe;             //   ... with its inverse block scale per row, for blgnn_linear_sp
 };
 
 // columns 4 l .. 4 l + 3 of the one-hot row of an atom
@@ -422,12 +425,20 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
             if (vec_out) *reinterpret_cast<float4 *>(dst) = v;
             else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
         }
-        if (A.y_amax) {
+        if (A.y_amax || (N == 256 && A.ysp)) {
             // the N4 lanes that store one row sit in one wavefront (N4 = 32 or 64): their maximum is the row's
             float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
 #pragma unroll
             for (int off = 1; off < N4; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, WAVE));
-            if (live && c4 == 0) A.y_amax[row] = mx;
+            if (live && c4 == 0 && A.y_amax) A.y_amax[row] = mx;
+            if (N == 256 && A.ysp && live) {
+                // the row is one 256-column scale block: the GMN propagator's GEMMs read it from here
+                float sc, inv;
+                pow2_scale(mx, sc, inv);
+                if (c4 == 0) A.yspe[(int64_t)row * A.ldyspe] = inv;
+                const f32x4v sv = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+                sp_store4(A.ysp + (int64_t)row * A.ldysp, 4 * c4, sv);
+            }
         }
     }
     // ---- (4) fused readout: per-graph column sums of the staged tile, one atomic per (graph, column) and tile.
@@ -570,8 +581,11 @@ extern "C" int blgnn_gin_layer_h3(const int32_t *rowptr, const int32_t *col, int
                                   const void *w2_packed, const float *b2, int32_t N, float eps, int32_t act,
                                   const float *act_param, const float *bn_scale, const float *bn_shift,
                                   float *y, int64_t ldy, const int32_t *row_graph, const int32_t *seg,
-                                  float *pooled, int64_t ldp, int32_t pool_kind, float *y_row_amax, void *stream) {
+                                  float *pooled, int64_t ldp, int32_t pool_kind, float *y_row_amax, void *y_sp,
+                                  int64_t ld_ysp, float *y_spe, int64_t ld_yspe, void *stream) {
     BLGNN_CHECK_ARG(n >= 0 && K > 0 && N > 0 && nnz >= 0, "gin_layer_h3: bad sizes");
+    BLGNN_CHECK_ARG(!y_sp || (N == SP_BLOCK && y_spe && ld_ysp >= 2 * SP_BLOCK && ld_ysp % 8 == 0 && aligned16(y_sp) && ld_yspe >= 1),
+                    "gin_layer_h3: sp output needs N == 256 and 16-byte aligned planes");
     BLGNN_CHECK_ARG(!pooled || (row_graph && seg && ldp >= N && (pool_kind == BLGNN_REDUCE_SUM || pool_kind == BLGNN_REDUCE_MEAN)),
                     "gin_layer_h3: fused readout needs row_graph, seg, ldp >= N and a reduce kind");
     if (n == 0) return BLGNN_OK;
@@ -592,6 +606,7 @@ extern "C" int blgnn_gin_layer_h3(const int32_t *rowptr, const int32_t *col, int
     A.codes = nullptr; A.n_attr = 0;
     A.row_graph = row_graph; A.seg = seg; A.pool = pooled; A.ldp = ldp; A.pool_mean = pool_kind == BLGNN_REDUCE_MEAN;
     A.y_amax = y_row_amax;
+    A.ysp = reinterpret_cast<_Float16 *>(y_sp); A.ldysp = ld_ysp; A.yspe = y_spe; A.ldyspe = ld_yspe;
     hipStream_t s = (hipStream_t)stream;
     const int k4 = K / 4;
     if (N == 256) {
@@ -631,6 +646,7 @@ extern "C" int blgnn_gin_layer_h3_codes(const int32_t *rowptr, const int32_t *co
     A.codes = reinterpret_cast<const uint2 *>(codes); A.n_attr = num_attr;
     A.row_graph = row_graph; A.seg = seg; A.pool = pooled; A.ldp = ldp; A.pool_mean = pool_kind == BLGNN_REDUCE_MEAN;
     A.y_amax = y_row_amax;
+    A.ysp = nullptr; A.ldysp = 0; A.yspe = nullptr; A.ldyspe = 0;
     for (int a = 0; a < 8; ++a) {
         const int o = a < num_attr ? code_offsets_host[a] : 0;
         BLGNN_CHECK_ARG(o >= 0 && o < 256, "gin_layer_h3_codes: attribute offset out of range");

@@ -1,0 +1,525 @@
+// f16x3 GEMM on PRE-SPLIT operands ("sp" format, sp_common.hpp): the GMN propagator's GEMMs over all atoms
+// (model/layers_gmn.py:19-26,39-47: f_message's first Linear, f_node's two Linears).
+//
+//   Y = epi( X[M,K] @ W[K,N] + bias + rowvec (x) rowvec_w )      epi = act, then affine
+//
+// with X given as fp16 piece planes + per-(row, 256-column block) power-of-two scales and Y written as fp32
+// rows, as the same sp format (for the next GEMM), or both.
+//
+// Why a second f16x3 GEMM next to linear_h3.hip (measured there, 462 k x 1024 x 1024): that kernel converts the
+// fp32 X tile to two fp16 images INSIDE the GEMM -- four of its eight waves do nothing else, every column block
+// of a row panel repeats the conversion, and its knock-outs show the operand streams (not the matrix cores)
+// setting the time.  Here the producer of X has already split it, so
+//   * both operand tiles of a K step arrive by LDS-DMA (global_load_lds_dwordx4: no registers, no conversion, no
+//     ds_write); the swizzle that makes the fragment reads conflict free is applied by choosing which 16-byte
+//     chunk of the 128-byte row segment each lane fetches;
+//   * all eight waves issue MFMAs (two per SIMD, 64 x 128 outputs each), the tile is 256 x 256 at K step 32:
+//     64 KB of operands per 12.6 MFLOP-x3 instead of 48 KB per 6.3;
+//   * the row-magnitude passes (blgnn_row_absmax, atomic row maxima in epilogues) disappear: scales travel with
+//     the data.
+// Block scales inside one accumulator: the accumulators hold sum_k x~ w~ in units of the CURRENT block's scale;
+// at a block boundary (every 8 K steps) they are multiplied by the exact power of two u_next / u_cur.  u follows
+// the blocks' scales but never exceeds 2^40 x the smallest scale seen (a block 2^40 below the row's largest
+// contributes < 2^-40 of the dot product whatever is done with it), so nothing overflows on zero blocks or on
+// rows spanning the whole fp32 range.
+// Operand roles: W fragments are the MFMA A operand and X fragments the B operand, so a lane owns ONE row m of a
+// 32 x 32 block (scale bookkeeping = one register per row block) and four consecutive columns per accumulator
+// quad (epilogue parameters and stores are float4 wide).
+#include <cstdlib>
+#include "linear_common.hpp"
+#include "sp_common.hpp"
+
+namespace blgnn {
+
+struct LinearSpArgs {
+    const _Float16 *xs; int64_t ldxs;      // sp planes of X: fp16 elements per row (2 K for a dense matrix)
+    const float *xe; int64_t ldxe;         // inverse block scales [M][K / 256]
+    const _Float16 *wp;                    // blgnn_pack_weight_sp image
+    float *y; int64_t ldy;                 // fp32 output (nullable)
+    _Float16 *ys; int64_t ldys;            // sp output (nullable) ...
+    float *ye; int64_t ldye;               // ... and its inverse block scales [M][N / 256]
+    int32_t M, N, K;
+    const float *rowvec, *rowvec_w;
+    Epilogue epi;
+};
+
+constexpr int SP_BM = 256, SP_BN = 256, SP_BK = 32;
+constexpr int SP_ROWB = 128;                       // LDS row: [h1 x 32 | h2 x 32] fp16 = eight 16-byte chunks
+constexpr int SP_XST = SP_BM * SP_ROWB;            // 32 KB
+constexpr int SP_WST = SP_BN * SP_ROWB;            // 32 KB
+constexpr int SP_STAGE = SP_XST + SP_WST;          // 64 KB
+constexpr int SP_OSTRIDE = 528;                    // epilogue staging row: 512 B + 16
+constexpr int SP_OWAVE = 32 * SP_OSTRIDE;          // one wave's staging tile (32 rows x 128 columns)
+constexpr int SP_OSTG = 8 * SP_OWAVE;              // 132 KB >= two operand stages (128 KB); behind it:
+constexpr int SP_NPAR = 5;                         // bias, rowvec_w, bn scale, bn shift, PReLU slope
+constexpr int SP_LDS = SP_OSTG + SP_NPAR * SP_BN * 4 + SP_BM * 4;
+static_assert(SP_OSTG >= 2 * SP_STAGE, "staging area must cover the operand stages");
+
+#ifndef SP_X_AUX
+#define SP_X_AUX 0
+#endif
+typedef __attribute__((address_space(3))) void sp_lds_void;
+typedef __attribute__((address_space(1))) void sp_glb_void;
+
+// ---- weight packing: W[K,N] fp32 -> header + [N / 256][K / 32] tile images of 32 KB --------------------------
+// tile image = the LDS image of (column block, K step): [column 256][slot 8][8 fp16], slot = chunk ^ ((column >> 1) & 7),
+// chunks 0-3 = high pieces of k = 0..31, chunks 4-7 = low pieces; scaled by the power of two that moves the
+// largest |w| into [2^14, 2^15) (inverse in the header); zero filled past K.
+__global__ void k_pack_sp(const float *__restrict__ w, int64_t ldw, int K, int N, int KS,
+                          const unsigned *__restrict__ amax_bits, _Float16 *__restrict__ out) {
+    float scale, inv;
+    pow2_scale(__uint_as_float(*amax_bits), scale, inv);
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one (column, 8-k group): high AND low word
+    if (idx == 0) *reinterpret_cast<float *>(out) = inv;
+    if (idx >= (int64_t)(N / SP_BN) * KS * SP_BN * 4) return;
+    const int kc = (int)(idx & 3), r = (int)((idx >> 2) & (SP_BN - 1));
+    const int64_t tile = idx >> 10;
+    const int ks = (int)(tile % KS), nb = (int)(tile / KS);
+    const int n = nb * SP_BN + r, sw = (r >> 1) & 7;
+    f16x8 p[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = ks * SP_BK + kc * 8 + j;
+        const Split2 sp = split2(k < K ? w[(int64_t)k * ldw + n] * scale : 0.f);
+        p[0][j] = sp.h1; p[1][j] = sp.h2;
+    }
+    _Float16 *base = out + HHDR + tile * (SP_WST / 2) + r * 64;
+    *reinterpret_cast<f16x8 *>(base + ((kc ^ sw) << 3)) = p[0];
+    *reinterpret_cast<f16x8 *>(base + (((kc + 4) ^ sw) << 3)) = p[1];
+}
+
+__global__ void k_absmax_sp(const float *__restrict__ w, int64_t ldw, int K, int N, unsigned *out) {
+    float m = 0.f;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < (int64_t)K * N;
+         idx += (int64_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(w[(idx / N) * ldw + idx % N]));
+    m = group_max(m, WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// ---- fp32 rows -> sp format (for producers that do not write it themselves): one wave per (row, block) ---------
+__global__ void __launch_bounds__(256) k_split_sp(const float *__restrict__ x, int64_t ldx, int M, int KB,
+                                                  _Float16 *__restrict__ xs, int64_t ldxs,
+                                                  float *__restrict__ xe, int64_t ldxe) {
+    const int lane = threadIdx.x & 63;
+    const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= (int64_t)M * KB) return;
+    const int m = (int)(unit / KB), kb = (int)(unit % KB);
+    const float4 v = *reinterpret_cast<const float4 *>(x + (int64_t)m * ldx + kb * SP_BLOCK + lane * 4);
+    float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    mx = group_max(mx, WAVE);
+    float s, inv;
+    pow2_scale(mx, s, inv);
+    if (lane == 0) xe[(int64_t)m * ldxe + kb] = inv;
+    const f32x4v sv = {v.x * s, v.y * s, v.z * s, v.w * s};
+    sp_store4(xs + (int64_t)m * ldxs + kb * (2 * SP_BLOCK), lane * 4, sv);
+}
+
+// ---- sp format -> fp32 rows (tests, and consumers outside the GEMM) ------------------------------------------
+__global__ void __launch_bounds__(256) k_join_sp(const _Float16 *__restrict__ xs, int64_t ldxs,
+                                                 const float *__restrict__ xe, int64_t ldxe, int M, int KB,
+                                                 float *__restrict__ x, int64_t ldx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= (int64_t)M * KB) return;
+    const int m = (int)(unit / KB), kb = (int)(unit % KB);
+    const float inv = xe[(int64_t)m * ldxe + kb];
+    const int col = lane * 4;
+    const _Float16 *src = xs + (int64_t)m * ldxs + kb * (2 * SP_BLOCK) + (col >> 5) * 64 + (col & 31);
+    const f16x4 h1 = *reinterpret_cast<const f16x4 *>(src), h2 = *reinterpret_cast<const f16x4 *>(src + 32);
+    float4 o;
+    o.x = ((float)h1[0] + (float)h2[0]) * inv; o.y = ((float)h1[1] + (float)h2[1]) * inv;
+    o.z = ((float)h1[2] + (float)h2[2]) * inv; o.w = ((float)h1[3] + (float)h2[3]) * inv;
+    *reinterpret_cast<float4 *>(x + (int64_t)m * ldx + kb * SP_BLOCK + col) = o;
+}
+
+// ---- the GEMM --------------------------------------------------------------------------------------------------
+// GEN = false: identity / relu only (the GMN GEMMs); GEN = true: every activation id (expf / tanhf inlined 128 times)
+template <bool GEN>
+__global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
+    extern __shared__ float4 sp_smem[];
+    char *smem = reinterpret_cast<char *>(sp_smem);
+    float *cpar = reinterpret_cast<float *>(smem + SP_OSTG);                  // [SP_NPAR][256]   (epilogue only)
+    unsigned *rowmax = reinterpret_cast<unsigned *>(cpar + SP_NPAR * SP_BN);   // [256] bits of max |y| per row
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform by construction: keep it scalar
+    const int nb = P.N / SP_BN;
+    int tile;
+    {   // blocks b, b + 8, ... share an XCD: give each XCD a contiguous run of tiles (row-panel major), so the
+        // column blocks of one row panel read it from the same L2
+        const int nblk = gridDim.x, b = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = b & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int m0 = (tile / nb) * SP_BM, cb = tile % nb, n0 = cb * SP_BN;
+    const int KS = P.K / SP_BK;
+
+    // ---- LDS-DMA plan: per K step this wave brings 32 X rows and 32 W columns (4 + 4 pieces of 1 KB) ----------
+    // piece i of X: rows 32 wid + 8 i + (lane >> 3), LDS slot lane & 7 <- global chunk slot ^ ((row >> 1) & 7).
+    // Buffer addressing: wave-uniform parts (tile base, row group, K step) ride in the resource / the scalar
+    // offset, the lane's part is one 32-bit register for even and one for odd pieces; rows past M lie beyond
+    // num_records and arrive as zeros.
+    const int64_t rowb = P.ldxs * 2;
+    const int rows_in = min(SP_BM, P.M - m0);
+    const __amdgpu_buffer_rsrc_t RX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(P.xs) + (int64_t)m0 * rowb), 0,
+        (int)((int64_t)(rows_in - 1) * rowb + (int64_t)P.K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t RW = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(P.wp + HHDR) + (size_t)cb * KS * SP_WST), 0,
+        KS * SP_WST, 0x00020000);
+    const int xv0 = (lane >> 3) * (int)rowb + (((lane & 7) ^ (lane >> 4)) << 4);
+    const int xv1 = (lane >> 3) * (int)rowb + (((lane & 7) ^ (lane >> 4) ^ 4) << 4);
+    const int wv = lane * 16;
+    const int xs0 = 32 * wid * (int)rowb;
+    auto dma = [&](int ks) {
+        char *st = smem + (ks & 1) * SP_STAGE;
+#ifndef SP_KNOCK_XDMA
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(RX, (sp_lds_void *)(st + (32 * wid + 8 * i) * SP_ROWB), 16,
+                                                     (i & 1) ? xv1 : xv0, xs0 + 8 * i * (int)rowb + ks * SP_ROWB, 0, SP_X_AUX);
+#endif
+#ifndef SP_KNOCK_WDMA
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(RW, (sp_lds_void *)(st + SP_XST + wid * 4096 + i * 1024), 16, wv,
+                                                     ks * SP_WST + wid * 4096 + i * 1024, 0, 0);
+#endif
+    };
+
+    // ---- this wave's 64 x 128 outputs: row blocks ib (2), column blocks jb (4) ----------------------------------
+    const int fi = lane & 31, fh = lane >> 5, wm = wid >> 1, wn = wid & 1;
+    const int sw = (fi >> 1) & 7;
+    const int xrow = (wm * 64 + fi) * SP_ROWB, wrow = SP_XST + (wn * 128 + fi) * SP_ROWB;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ib][jb][r] = 0.f;
+
+    dma(0);                                                 // K step 0 requested before anything else
+
+    // epilogue parameters of this thread's column: fetched now (behind the ring prologue's requests), parked in
+    // registers (the ring owns all of LDS), written to LDS after the last K step
+    float par[SP_NPAR] = {0.f, 0.f, 1.f, 0.f, 0.f};
+    if (tid < SP_BN) {
+        const int n = n0 + tid;
+        if (P.epi.bias) par[0] = P.epi.bias[n];
+        if (P.rowvec_w) par[1] = P.rowvec_w[n];
+        if (P.epi.bn_scale) par[2] = P.epi.bn_scale[n];
+        if (P.epi.bn_scale && P.epi.bn_shift) par[3] = P.epi.bn_shift[n];
+        if (P.epi.act == BLGNN_ACT_PRELU && P.epi.act_param) par[4] = P.epi.act_param[n];
+    }
+
+    // scale bookkeeping per owned row: the blocks' inverse scales are powers of two; their biased exponent fields
+    // (8 bits each, K <= 2048: at most 8 blocks) are packed into one 64-bit word per row, so the main loop issues
+    // no vector-memory instruction but the ring's -- a load the loop waited on would drain the ring
+    const int KB = P.K / SP_BLOCK;
+    unsigned long long epack[2];
+    int eiu[2], eimax[2];
+    float rv[2];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+        const int m = min(m0 + wm * 64 + 32 * ib + fi, P.M - 1);
+        const float *xep = P.xe + (int64_t)m * P.ldxe;
+        // unconditional clamped loads (a guarded load becomes a branch with its own full wait: eight dependent
+        // round trips per row block); blocks past KB repeat the last one and are never consulted
+        float ev[8];
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) ev[kb] = xep[kb < KB ? kb : KB - 1];
+        unsigned long long pk = 0;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) pk |= (unsigned long long)(__float_as_uint(ev[kb]) >> 23) << (8 * kb);
+        epack[ib] = pk;
+        eiu[ib] = eimax[ib] = (int)(pk & 0xffu);
+        const int mr = m0 + wm * 64 + 32 * ib + fi;
+        rv[ib] = P.rowvec ? P.rowvec[mr < P.M ? mr : P.M - 1] : 0.f;
+    }
+    float winv = *reinterpret_cast<const float *>(P.wp);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // K step 0 has landed (and the plain loads above)
+    // the compiler does not see that wait: pin every loaded value here, or it places its own full wait at the
+    // first use -- inside the loop (draining the ring at every block boundary) or in front of the epilogue
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+        unsigned lo = (unsigned)epack[ib], hi = (unsigned)(epack[ib] >> 32);
+        asm volatile("" : "+v"(lo), "+v"(hi), "+v"(rv[ib]));
+        epack[ib] = ((unsigned long long)hi << 32) | lo;
+    }
+#pragma unroll
+    for (int j = 0; j < SP_NPAR; ++j) asm volatile("" : "+v"(par[j]));
+    asm volatile("" : "+v"(winv));
+    lds_barrier();
+
+    for (int ks = 0; ks < KS; ++ks) {
+        const char *cur = smem + (ks & 1) * SP_STAGE;
+#ifndef SP_KNOCK_DMA
+        if (ks + 1 < KS) dma(ks + 1);                  // the other stage: last read during step ks - 1
+#endif
+        if ((ks & 7) == 0 && ks > 0) {
+            // block boundary: re-express the accumulators in the next block's unit
+            const int kb = ks >> 3;
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                const int ei = (int)((epack[ib] >> (8 * kb)) & 0xffu);
+                eimax[ib] = max(eimax[ib], ei);
+                const int enew = max(ei, eimax[ib] - 40);
+                const int d = max(eiu[ib] - enew, -126);
+                eiu[ib] = enew;
+                const float ratio = __uint_as_float((unsigned)(127 + d) << 23);
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[ib][jb][r] *= ratio;
+            }
+        }
+        f16x8 fw[2][4][2], fx[2][2][2];
+        auto read_frags = [&](int s, f16x8 (&a)[4][2], f16x8 (&b)[2][2]) {
+            const int c1 = ((2 * s + fh) ^ sw) << 4, c2 = ((4 + 2 * s + fh) ^ sw) << 4;
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                b[ib][0] = *reinterpret_cast<const f16x8 *>(cur + xrow + c1 + 32 * ib * SP_ROWB);
+                b[ib][1] = *reinterpret_cast<const f16x8 *>(cur + xrow + c2 + 32 * ib * SP_ROWB);
+            }
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                a[jb][0] = *reinterpret_cast<const f16x8 *>(cur + wrow + c1 + 32 * jb * SP_ROWB);
+                a[jb][1] = *reinterpret_cast<const f16x8 *>(cur + wrow + c2 + 32 * jb * SP_ROWB);
+            }
+        };
+        read_frags(0, fw[0], fx[0]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s + 1 < 2) read_frags(s + 1, fw[(s + 1) & 1], fx[(s + 1) & 1]);
+            f16x8 (&a)[4][2] = fw[s & 1];
+            f16x8 (&b)[2][2] = fx[s & 1];
+            // term-major order, the small terms first: eight MFMAs between two writes of the same accumulator
+#define SP_TERM(QW, QX)                                                                                   \
+    _Pragma("unroll") for (int ib = 0; ib < 2; ++ib) _Pragma("unroll") for (int jb = 0; jb < 4; ++jb)      \
+        acc[ib][jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[jb][QW], b[ib][QX], acc[ib][jb], 0, 0, 0);
+#ifndef SP_KNOCK_MFMA
+            SP_TERM(1, 0)
+            SP_TERM(0, 1)
+            SP_TERM(0, 0)
+#else
+            acc[0][0][0] += (float)a[0][0][0] + (float)b[0][0][0];
+#endif
+#undef SP_TERM
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of step ks + 1 have landed
+        lds_barrier();                                      // stage ks & 1 fully read, stage (ks + 1) & 1 complete
+    }
+
+    // park the epilogue parameters behind the staging tiles
+    if (tid < SP_BN) {
+#pragma unroll
+        for (int j = 0; j < SP_NPAR; ++j) cpar[j * SP_BN + tid] = par[j];
+        rowmax[tid] = 0u;
+    }
+    lds_barrier();
+
+    // ================================================ epilogue ================================================
+    // lane (fi, fh) of block (ib, jb) holds row 32 ib + fi, columns 32 jb + 8 g + 4 fh + (0..3), g = register quad
+    const int act = P.epi.act;
+    const bool relu = act == BLGNN_ACT_RELU;                   // GEN = false: relu or identity
+    const int mrow0 = m0 + wm * 64 + fi;
+    float rsc[2];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) rsc[ib] = __uint_as_float((unsigned)eiu[ib] << 23) * winv;
+    // straight-line: the staged parameters hold neutral values where the caller passed none (scale 1, shift 0,
+    // rank-1 factor 0), so no branch splits the accumulators' live ranges; row blocks innermost, so a column
+    // group's parameters are read once
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nl = wn * 128 + 32 * jb + 8 * g + 4 * fh;
+            const float4 b4 = *reinterpret_cast<const float4 *>(cpar + nl);
+            const float4 w4 = *reinterpret_cast<const float4 *>(cpar + SP_BN + nl);
+            const float4 s4 = *reinterpret_cast<const float4 *>(cpar + 2 * SP_BN + nl);
+            const float4 t4 = *reinterpret_cast<const float4 *>(cpar + 3 * SP_BN + nl);
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
+            const float sc[4] = {s4.x, s4.y, s4.z, s4.w}, sh[4] = {t4.x, t4.y, t4.z, t4.w};
+            float sl[4] = {0.f, 0.f, 0.f, 0.f};
+            if (GEN) {
+                const float4 p4 = *reinterpret_cast<const float4 *>(cpar + 4 * SP_BN + nl);
+                sl[0] = p4.x; sl[1] = p4.y; sl[2] = p4.z; sl[3] = p4.w;
+            }
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = acc[ib][jb][4 * g + q] * rsc[ib];
+                    v = fmaf(rv[ib], ww[q], v + bb[q]);
+                    if (GEN) v = apply_act(v, act, sl[q]);
+                    else v = (relu && !(v > 0.f)) ? 0.f : v;
+                    acc[ib][jb][4 * g + q] = fmaf(v, sc[q], sh[q]);
+                }
+        }
+    // every wave passed the barrier that ended the last K step: the operand stages are free.  Wave-private
+    // staging tile (LDS operations of one wave complete in order: no barrier between its writes and reads).
+    char *stg = smem + wid * SP_OWAVE;
+    if (P.y) {
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = make_float4(acc[ib][jb][4 * g], acc[ib][jb][4 * g + 1], acc[ib][jb][4 * g + 2],
+                                                 acc[ib][jb][4 * g + 3]);
+                    *reinterpret_cast<float4 *>(stg + fi * SP_OSTRIDE + (32 * jb + 8 * g + 4 * fh) * 4) = v;
+                }
+            const int mb = m0 + wm * 64 + 32 * ib;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int t = lane + 64 * it, row = t >> 5, c4 = t & 31;
+                const float4 v = *reinterpret_cast<const float4 *>(stg + row * SP_OSTRIDE + c4 * 16);
+                if (mb + row < P.M)
+                    *reinterpret_cast<float4 *>(P.y + (int64_t)(mb + row) * P.ldy + n0 + wn * 128 + c4 * 4) = v;
+            }
+        }
+    }
+    if (P.ys) {
+        // block scale = the row's largest magnitude over the tile's 256 columns (this wave + its column neighbour)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            float mx = 0.f;
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[ib][jb][r]));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+            if (fh == 0) atomicMax(rowmax + wm * 64 + 32 * ib + fi, __float_as_uint(mx));
+        }
+        lds_barrier();
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            float s, inv;
+            pow2_scale(__uint_as_float(rowmax[wm * 64 + 32 * ib + fi]), s, inv);
+            const int m = mrow0 + 32 * ib;
+            if (wn == 0 && fh == 0 && m < P.M) P.ye[(int64_t)m * P.ldye + (n0 >> 8)] = inv;
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4v v = {acc[ib][jb][4 * g] * s, acc[ib][jb][4 * g + 1] * s, acc[ib][jb][4 * g + 2] * s,
+                                      acc[ib][jb][4 * g + 3] * s};
+                    const f16x4 h1 = __builtin_convertvector(v, f16x4);
+                    const f16x4 h2 = __builtin_convertvector(v - __builtin_convertvector(h1, f32x4v), f16x4);
+                    char *dst = stg + fi * SP_OSTRIDE + jb * 128 + (8 * g + 4 * fh) * 2;
+                    *reinterpret_cast<f16x4 *>(dst) = h1;
+                    *reinterpret_cast<f16x4 *>(dst + 64) = h2;
+                }
+            const int mb = m0 + wm * 64 + 32 * ib;
+            char *yrow = reinterpret_cast<char *>(P.ys) + ((n0 + wn * 128) >> 5) * 128;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int t = lane + 64 * it, row = t >> 5, pc = t & 31;
+                const float4 v = *reinterpret_cast<const float4 *>(stg + row * SP_OSTRIDE + pc * 16);
+                if (mb + row < P.M)
+                    *reinterpret_cast<float4 *>(yrow + (int64_t)(mb + row) * P.ldys * 2 + pc * 16) = v;
+            }
+        }
+    }
+}
+
+template <bool GEN>
+static int launch_linear_sp_t(const LinearSpArgs &P, hipStream_t s) {
+    static bool declared = false;
+    if (!declared) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_sp<GEN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS) != hipSuccess)
+            return fail(BLGNN_ERR_LAUNCH, "linear_sp: cannot raise the dynamic LDS limit to %d bytes", SP_LDS);
+        declared = true;
+    }
+    const int64_t blocks = (int64_t)((P.M + SP_BM - 1) / SP_BM) * (P.N / SP_BN);
+    hipLaunchKernelGGL(k_linear_sp<GEN>, dim3((unsigned)blocks), dim3(512), SP_LDS, s, P);
+    return launch_status("linear_sp");
+}
+
+static int launch_linear_sp(const LinearSpArgs &P, hipStream_t s) {
+    return P.epi.act <= BLGNN_ACT_RELU ? launch_linear_sp_t<false>(P, s) : launch_linear_sp_t<true>(P, s);
+}
+
+}  // namespace blgnn
+
+using namespace blgnn;
+
+extern "C" int64_t blgnn_packed_weight_sp_elems(int32_t K, int32_t N) {
+    if (K <= 0 || N <= 0 || N % SP_BN != 0) return -1;
+    return HHDR + ((int64_t)N / SP_BN) * (((int64_t)K + SP_BK - 1) / SP_BK) * (SP_WST / 2);   // fp16 elements
+}
+
+extern "C" int blgnn_pack_weight_sp(const float *w, int64_t ldw, int32_t K, int32_t N, void *out, void *stream) {
+    BLGNN_CHECK_ARG(w && out && K > 0 && N > 0 && ldw >= N, "pack_weight_sp: bad args");
+    BLGNN_CHECK_ARG(N % SP_BN == 0, "pack_weight_sp: N must be a multiple of 256");
+    BLGNN_CHECK_ARG(aligned16(out), "pack_weight_sp: out must be 16-byte aligned");
+    const int KS = (K + SP_BK - 1) / SP_BK;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned *amax = reinterpret_cast<unsigned *>(out) + 1;       // header word 1: scratch for the maximum's bits
+    if (hipMemsetAsync(out, 0, HHDR * 2, s) != hipSuccess) return fail(BLGNN_ERR_LAUNCH, "pack_weight_sp: memset failed");
+    const int64_t total = (int64_t)K * N;
+    hipLaunchKernelGGL(k_absmax_sp, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)), dim3(256), 0, s,
+                       w, ldw, K, N, amax);
+    const int64_t words = (int64_t)(N / SP_BN) * KS * SP_BN * 4;
+    hipLaunchKernelGGL(k_pack_sp, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, w, ldw, K, N, KS, amax,
+                       reinterpret_cast<_Float16 *>(out));
+    return launch_status("pack_weight_sp");
+}
+
+extern "C" int blgnn_split_rows_sp(const float *x, int64_t ldx, int32_t M, int32_t K, void *xs, int64_t ldxs,
+                                   float *xe, int64_t ldxe, void *stream) {
+    BLGNN_CHECK_ARG(M >= 0 && K > 0 && K % SP_BLOCK == 0, "split_rows_sp: K must be a positive multiple of 256");
+    if (M == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(x && xs && xe && ldx >= K && ldxs >= 2 * (int64_t)K && ldxe >= K / SP_BLOCK, "split_rows_sp: bad args");
+    BLGNN_CHECK_ARG(ldx % 4 == 0 && aligned16(x) && ldxs % 8 == 0 && aligned16(xs), "split_rows_sp: 16-byte alignment");
+    const int KB = K / SP_BLOCK;
+    const int64_t units = (int64_t)M * KB;
+    hipLaunchKernelGGL(k_split_sp, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, M, KB,
+                       reinterpret_cast<_Float16 *>(xs), ldxs, xe, ldxe);
+    return launch_status("split_rows_sp");
+}
+
+extern "C" int blgnn_join_rows_sp(const void *xs, int64_t ldxs, const float *xe, int64_t ldxe, int32_t M, int32_t K,
+                                  float *x, int64_t ldx, void *stream) {
+    BLGNN_CHECK_ARG(M >= 0 && K > 0 && K % SP_BLOCK == 0, "join_rows_sp: K must be a positive multiple of 256");
+    if (M == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(x && xs && xe && ldx >= K && ldxs >= 2 * (int64_t)K && ldxe >= K / SP_BLOCK, "join_rows_sp: bad args");
+    BLGNN_CHECK_ARG(ldx % 4 == 0 && aligned16(x) && ldxs % 8 == 0 && aligned16(xs), "join_rows_sp: 16-byte alignment");
+    const int KB = K / SP_BLOCK;
+    const int64_t units = (int64_t)M * KB;
+    hipLaunchKernelGGL(k_join_sp, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const _Float16 *>(xs), ldxs, xe, ldxe, M, KB, x, ldx);
+    return launch_status("join_rows_sp");
+}
+
+extern "C" int blgnn_linear_sp(const void *xs, int64_t ldxs, const float *xe, int64_t ldxe, const void *w_packed,
+                               float *y, int64_t ldy, void *ys, int64_t ldys, float *ye, int64_t ldye,
+                               int32_t M, int32_t N, int32_t K, const float *bias, const float *rowvec,
+                               const float *rowvec_w, int32_t act, const float *act_param,
+                               const float *bn_scale, const float *bn_shift, void *stream) {
+    BLGNN_CHECK_ARG(M >= 0 && N > 0 && K > 0, "linear_sp: bad sizes");
+    if (M == 0) return BLGNN_OK;
+    if (N % SP_BN != 0 || K % SP_BLOCK != 0)
+        return fail(BLGNN_ERR_UNSUPPORTED, "linear_sp: needs N %% 256 == 0 and K %% 256 == 0 (got N=%d K=%d); use "
+                    "blgnn_linear_h3 / blgnn_linear", N, K);
+    BLGNN_CHECK_ARG(xs && xe && w_packed && (y || ys), "linear_sp: null pointer");
+    BLGNN_CHECK_ARG(ldxs >= 2 * (int64_t)K && ldxs % 8 == 0 && aligned16(xs) && ldxe >= K / SP_BLOCK,
+                    "linear_sp: bad X planes (ldxs >= 2K, 16-byte aligned rows)");
+    BLGNN_CHECK_ARG(aligned16(w_packed), "linear_sp: packed weights must be 16-byte aligned");
+    BLGNN_CHECK_ARG(!y || (ldy >= N && ldy % 4 == 0 && aligned16(y)), "linear_sp: y must have 16-byte aligned rows");
+    BLGNN_CHECK_ARG(!ys || (ye && ldys >= 2 * (int64_t)N && ldys % 8 == 0 && aligned16(ys) && ldye >= N / SP_BLOCK),
+                    "linear_sp: bad Y planes");
+    BLGNN_CHECK_ARG(act >= 0 && act <= BLGNN_ACT_TANH, "linear_sp: bad activation id");
+    BLGNN_CHECK_ARG((rowvec == nullptr) == (rowvec_w == nullptr), "linear_sp: rowvec and rowvec_w go together");
+    BLGNN_CHECK_ARG(xs != ys, "linear_sp: x and y planes must not alias");
+    LinearSpArgs P;
+    P.xs = reinterpret_cast<const _Float16 *>(xs); P.ldxs = ldxs; P.xe = xe; P.ldxe = ldxe;
+    P.wp = reinterpret_cast<const _Float16 *>(w_packed);
+    P.y = y; P.ldy = ldy; P.ys = reinterpret_cast<_Float16 *>(ys); P.ldys = ldys; P.ye = ye; P.ldye = ldye;
+    P.M = M; P.N = N; P.K = K; P.rowvec = rowvec; P.rowvec_w = rowvec_w;
+    P.epi = Epilogue{bias, act_param, bn_scale, bn_shift, act};
+    return launch_linear_sp(P, (hipStream_t)stream);
+}

@@ -1,0 +1,32 @@
+// "sp" (split-plane) activation format: what the f16x3 GEMM of linear_sp.hip reads and what its producers write.
+//
+// An fp32 activation matrix X[M, K] (K % 256 == 0) is kept as
+//   xs : fp16 [M][K / 32][64]   per row and 32-column chunk: 32 high pieces h1, then 32 low pieces h2 (128 B =
+//                               one cache line per (row, K step of the GEMM));
+//   xe : fp32 [M][K / 256]      inverse of the power-of-two scale of every (row, 256-column block):
+//                               x[m, k] = (h1 + h2) * xe[m][k / 256],  h1 = fp16(x * s), h2 = fp16(x * s - h1),
+//                               s = 1 / xe chosen so that the block's largest magnitude lies in [2^14, 2^15)
+// -- the same 4 bytes per element as fp32, the same 22 significand bits as the in-kernel split of linear_h3.hip
+// (h3_common.hpp), but formed ONCE by the kernel that produces X (its epilogue sees whole 256-column blocks of
+// a row) instead of by every column block of every GEMM that reads X.  Block scales instead of one scale per
+// row: no producer needs to know the other producers' columns (the GMN f_node input [x | S | u] has three), no
+// pass over finished rows, and a block 2^13 below its row's maximum keeps its low-order bits.
+#pragma once
+#include "h3_common.hpp"
+
+namespace blgnn {
+
+constexpr int SP_CHUNK = 32;              // columns per chunk
+constexpr int SP_BLOCK = 256;             // columns per scale block
+
+// lane-group helper for kernels whose lanes own 4 consecutive columns (float4) of a row: writes the two 8-byte
+// piece groups of those columns.  `col` = column inside the row (multiple of 4), v already scaled.
+__device__ __forceinline__ void sp_store4(_Float16 *__restrict__ row, int col, const f32x4v v) {
+    const f16x4 h1 = __builtin_convertvector(v, f16x4);
+    const f16x4 h2 = __builtin_convertvector(v - __builtin_convertvector(h1, f32x4v), f16x4);
+    _Float16 *dst = row + (col >> 5) * 64 + (col & 31);
+    *reinterpret_cast<f16x4 *>(dst) = h1;
+    *reinterpret_cast<f16x4 *>(dst + 32) = h2;
+}
+
+}  // namespace blgnn

@@ -148,7 +148,10 @@ int blgnn_gin_layer_x6(const int32_t *rowptr, const int32_t *col, int64_t nnz,
  * One hardware float atomic per (graph, column, tile): a graph covered by <= 2 tiles sums in an
  * order-independent way; larger ones may differ in the last bit between runs.  pooled == NULL: off.
  * y_row_amax (optional, [n]): receives max |y[i, :]| of every row -- the row magnitudes a following
- * blgnn_linear_h3 on y normalises by (the GMN message GEMM), without a pass over y. */
+ * blgnn_linear_h3 on y normalises by (the GMN message GEMM), without a pass over y.
+ * y_sp / y_spe (optional, N == 256 only; blgnn_gin_layer_h3): y additionally in the sp format of
+ * blgnn_linear_sp (below), ld_ysp in fp16 elements, one inverse block scale per row at y_spe[i * ld_yspe]:
+ * the GMN propagator's GEMMs read the layer output from there with no conversion pass. */
 int64_t blgnn_packed_weight_h3_elems(int32_t K, int32_t N);
 int blgnn_pack_weight_h3(const float *w, int64_t ldw, int32_t K, int32_t N, void *out,
                          void *stream);
@@ -159,7 +162,7 @@ int blgnn_gin_layer_h3(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                        const float *act_param, const float *bn_scale,
                        const float *bn_shift, float *y, int64_t ldy, const int32_t *row_graph,
                        const int32_t *seg, float *pooled, int64_t ldp, int32_t pool_kind,
-                       float *y_row_amax, void *stream);
+                       float *y_row_amax, void *y_sp, int64_t ld_ysp, float *y_spe, int64_t ld_yspe, void *stream);
 
 /* blgnn_gin_layer_h3 for the FIRST lower layer with categorical input: instead of the one-hot rows
  * x[n, F_in] (utils/data/representation_node_feat.py:86-97: one block per attribute, one 1 per block)
@@ -271,11 +274,13 @@ int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col, int64_t nnz,
  * y[i] = sum_{e: key_e = i} relu(p[i] + q[nbr_e])  (self loops kept).
  * row_amax (optional, [n], initialised by the caller): row_amax[i] = max(row_amax[i], max_c y[i, c]) by atomic
  * maximum -- one of the three producers of the f_node input's row magnitudes (blgnn_linear_h3), so that no
- * pass over the [n, 4D] buffer is needed. */
+ * pass over the [n, 4D] buffer is needed.
+ * y_sp / y_spe (optional, d % 256 == 0): the result in the sp format of blgnn_linear_sp (f_node's first Linear
+ * reads it); y may then be NULL. */
 int blgnn_edge_relu_sum(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                         const float *p, int64_t ldp, const float *q, int64_t ldq,
                         float *y, int64_t ldy, int32_t n, int32_t d, float *row_amax,
-                        void *stream);
+                        void *y_sp, int64_t ld_ysp, float *y_spe, int64_t ld_yspe, void *stream);
 /* row degree as float (for the deg_i * b2 term of the restructured message) */
 int blgnn_row_degree(const int32_t *rowptr, int32_t n, float *deg, void *stream);
 
@@ -350,6 +355,38 @@ int blgnn_linear_h3(const float *x, int64_t ldx, const float *row_amax, const vo
                     const float *rowvec, const float *rowvec_w, int32_t act,
                     const float *act_param, const float *bn_scale, const float *bn_shift,
                     void *stream);
+
+/* ---- f16x3 GEMM on pre-split activations ("sp" format) -------------------- */
+
+/* The GEMMs of the GMN propagator over all atoms (model/layers_gmn.py:19-26,39-47: f_message's first
+ * Linear, f_node's two Linears; model/layers_util.py:44-57) with the fp32 -> two-fp16-piece conversion of
+ * the activations done ONCE by the kernel that produces them instead of inside every GEMM that reads them.
+ *
+ * sp format of an activation matrix X[M, K], K % 256 == 0 (csrc/sp_common.hpp):
+ *   xs: fp16, row m at xs + m * ldxs (ldxs >= 2 K elements, rows 16-byte aligned); per 32-column chunk c of a
+ *       row 64 values: the 32 high pieces h1 of columns 32c..32c+31, then their 32 low pieces h2;
+ *   xe: fp32 [M][K / 256] (row stride ldxe): x[m, k] = (h1 + h2) * xe[m][k / 256]; 1 / xe is the power of two
+ *       that moves the block's largest magnitude into [2^14, 2^15).
+ * A column range that starts and ends on multiples of 256 is again an sp matrix (xs + 2 * c0, xe + c0 / 256):
+ * producers write their slices of the f_node input [x | S | u] independently.
+ *
+ * blgnn_split_rows_sp / blgnn_join_rows_sp convert fp32 rows to / from the format (one streaming pass).
+ * blgnn_pack_weight_sp: W[K, N] fp32 (N % 256 == 0) -> the tile-ordered two-piece image the GEMM streams.
+ * blgnn_linear_sp: epi(X @ W + bias + rowvec (x) rowvec_w) as three fp16 MFMA products per fp32 product
+ * (fp32-equivalent, see blgnn_linear_h3), 256 x 256 tiles, both operands by LDS-DMA.  The result goes to
+ * y (fp32 rows, ldy % 4 == 0), to ys / ye (sp format) or to both; pass NULL for the one not wanted.
+ * Needs N % 256 == 0 and K % 256 == 0 (K <= 2048); other shapes: BLGNN_ERR_UNSUPPORTED (use blgnn_linear_h3). */
+int64_t blgnn_packed_weight_sp_elems(int32_t K, int32_t N);
+int blgnn_pack_weight_sp(const float *w, int64_t ldw, int32_t K, int32_t N, void *out, void *stream);
+int blgnn_split_rows_sp(const float *x, int64_t ldx, int32_t M, int32_t K, void *xs, int64_t ldxs,
+                        float *xe, int64_t ldxe, void *stream);
+int blgnn_join_rows_sp(const void *xs, int64_t ldxs, const float *xe, int64_t ldxe, int32_t M, int32_t K,
+                       float *x, int64_t ldx, void *stream);
+int blgnn_linear_sp(const void *xs, int64_t ldxs, const float *xe, int64_t ldxe, const void *w_packed,
+                    float *y, int64_t ldy, void *ys, int64_t ldys, float *ye, int64_t ldye,
+                    int32_t M, int32_t N, int32_t K, const float *bias, const float *rowvec,
+                    const float *rowvec_w, int32_t act, const float *act_param,
+                    const float *bn_scale, const float *bn_shift, void *stream);
 
 /* ---- GMN cross-graph attention ------------------------------------------ */
 

@@ -1,0 +1,168 @@
+"""GPU parity of the pre-split ("sp") GEMM pipeline of the GMN propagator (include/blgnn.h: blgnn_linear_sp,
+blgnn_split_rows_sp / blgnn_join_rows_sp, the sp epilogues of blgnn_edge_relu_sum and blgnn_gin_layer_h3):
+every piece against the fp64 oracle at the 1e-5 bar, then the whole GMN models at d=256 / d=512 with the
+pipeline forced on (reference: model/layers_gmn.py:34-84, model/layers_util.py:44-57)."""
+
+import pytest
+import torch
+
+import blgnn
+import oracle
+from blgnn import ops
+from helpers import TOL, max_err
+from test_gpu_ops import molecule_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _row_rel(got, ref):
+    """largest error of any row relative to that row's largest reference magnitude"""
+    ref = ref.double()
+    err = (got.detach().cpu().double() - ref).abs().amax(dim=1)
+    scale = ref.abs().amax(dim=1)
+    live = scale > 0
+    return float((err[live] / scale[live]).max()) if bool(live.any()) else 0.0
+
+
+def test_split_join_round_trip(device):
+    """fp32 -> two fp16 pieces + block scale -> fp32: 22 significand bits relative to the block maximum, magnitudes
+    from 1e-25 to 1e25 (the power-of-two scale is clamped to 2^+-95, h3_common.hpp: pow2_scale), zero blocks, blocks
+    decades apart inside a row, a column slice of a wider sp matrix"""
+    M, K = 1000, 768
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, K, generator=g) * torch.logspace(-25, 25, M).view(-1, 1)
+    x[:, 256:512] *= 1e-6
+    x[7] = 0.0
+    x[9, 512:] = 0.0
+    x[::5] *= torch.logspace(-5, 0, K).view(1, -1)
+    xd = x.to(device)
+    sp = ops.split_rows_sp(xd)
+    back = ops.join_rows_sp(sp).cpu()
+    blocks = x.view(M, 3, 256)
+    err = (back.view(M, 3, 256).double() - blocks.double()).abs().amax(dim=2)
+    bmax = blocks.abs().amax(dim=2).double()
+    assert bool((err <= bmax * 2.0 ** -21).all())
+    assert float(back[7].abs().max()) == 0.0 and float(back[9, 512:].abs().max()) == 0.0
+    # producers fill column slices of one wide matrix independently
+    wide = ops.SpRows(M, 4 * 256, device)
+    ops.split_rows_sp(xd[:, 256:512].contiguous(), out=wide.cols(512, 768))
+    assert torch.equal(ops.join_rows_sp(wide.cols(512, 768)).cpu(), back[:, 256:512])
+    with pytest.raises(ValueError):
+        wide.cols(100, 356)
+
+
+@pytest.mark.parametrize("M,K,N,act", [(300, 256, 256, "identity"), (1000, 512, 512, "relu"), (515, 1024, 256, "relu"),
+                                       (257, 256, 1024, "tanh"), (64, 2048, 256, "prelu")])
+def test_linear_sp(device, M, K, N, act):
+    """epi(X @ W + bias + rowvec (x) rowvec_w) from sp operands == fp64, as fp32 rows AND as sp output; ragged M,
+    every activation, eval-BN affine"""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(K, N, generator=g) / K ** 0.5
+    b, rv, rw = torch.randn(N, generator=g) * 0.1, torch.rand(M, generator=g) * 3, torch.randn(N, generator=g) * 0.1
+    slope, scale, shift = torch.rand(N, generator=g), torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    D = lambda t: t.double()
+    ref = D(x) @ D(w) + D(b) + D(rv).view(-1, 1) * D(rw).view(1, -1)
+    ref = oracle.apply_act(ref, act, D(slope)) * D(scale) + D(shift)
+    dv = lambda t: t.to(device)
+    xs = ops.split_rows_sp(dv(x))
+    out_sp = ops.SpRows(M, N, device)
+    y, _ = ops.linear_sp(xs, dv(w), dv(b), act=act, act_param=dv(slope), bn_scale=dv(scale), bn_shift=dv(shift),
+                         rowvec=dv(rv), rowvec_w=dv(rw), out_sp=out_sp, f32=True)
+    assert max_err(y, ref) < TOL
+    assert max_err(ops.join_rows_sp(out_sp), ref) < TOL
+    # fp32 only, into a column slice of a wider buffer
+    widey = torch.zeros(M, N + 8, device=device)
+    ops.linear_sp(xs, dv(w), dv(b), act=act, act_param=dv(slope), bn_scale=dv(scale), bn_shift=dv(shift),
+                  rowvec=dv(rv), rowvec_w=dv(rw), out=widey[:, 4:4 + N])
+    assert torch.equal(widey[:, 4:4 + N], y) and float(widey[:, :4].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("xs,ws", [(1e-6, 1.0), (3e4, 1.0), (1.0, 1e-5), (1.0, 300.0), (1e5, 1e-4), (1e-20, 1e10)])
+def test_linear_sp_range(device, xs, ws):
+    """block scales inside one accumulator: tiny / huge activations and weights, rows and blocks of very different
+    magnitude in one tile, zero blocks in front of, between and behind live ones, six decades inside a block"""
+    M, N, K = 1200, 256, 1024
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(M, K, generator=g) * xs
+    x[::3] *= torch.logspace(-6, 0, K).view(1, -1)
+    x[1::7] *= 1e-4
+    x[2::11, 256:512] *= 1e-9                      # a block nine decades below its neighbours
+    x[3::13, :256] = 0.0                           # zero block first
+    x[4::13, 256:768] = 0.0                        # zero blocks in the middle
+    x[6::13, 768:] = 0.0                           # zero block last
+    x[5] = 0.0
+    w = torch.randn(K, N, generator=g) / K ** 0.5 * ws
+    ref = x.double() @ w.double()
+    y, _ = ops.linear_sp(ops.split_rows_sp(x.to(device)), w.to(device))
+    assert bool(torch.isfinite(y).all())
+    assert _row_rel(y, ref) < TOL
+    assert float(y[5].abs().max()) == 0.0
+
+
+def test_linear_sp_unsupported_shapes_raise(device):
+    x = ops.split_rows_sp(torch.randn(64, 256, device=device))
+    with pytest.raises(ValueError):
+        ops.pack_weight_sp(torch.randn(256, 192, device=device))
+    with pytest.raises(ValueError):
+        ops.SpRows(8, 300, device)
+    with pytest.raises(ValueError):
+        ops.linear_sp(x, torch.randn(512, 256, device=device))
+
+
+@pytest.mark.parametrize("d", [256, 512, 1024])
+def test_edge_relu_sum_sp(device, d):
+    """sum_e relu(P_i + Q_j) written straight into the sp format == the fp32 result == oracle"""
+    ei, _, n = molecule_graph(41, 17)
+    g = torch.Generator().manual_seed(d)
+    p, q = torch.randn(n, d, generator=g), torch.randn(n, d, generator=g)
+    p[3] = -100.0                                   # a row whose relus are all zero
+    row, col = ei[1], ei[0]
+    ref = torch.zeros(n, d, dtype=torch.float64).index_add_(0, row, torch.relu(p.double()[row] + q.double()[col]))
+    csr = ops.csr_from_edge_index(ei.to(device), n)
+    wide = ops.SpRows(n, 2 * d, device)
+    ops.edge_relu_sum(csr, p.to(device), q.to(device), out_sp=wide.cols(d, 2 * d))
+    got = ops.join_rows_sp(wide.cols(d, 2 * d))
+    assert max_err(got, ref) < TOL
+    plain = ops.edge_relu_sum(csr, p.to(device), q.to(device))
+    assert _row_rel(got, plain.cpu()) < 2.0 ** -21
+
+
+def test_gin_layer_h3_sp_output(device):
+    """the fused GIN layer (N = 256) writes its result as fp32 rows and, from the same registers, as sp planes"""
+    ei, _, n = molecule_graph(53, 19)
+    K = N = 256
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, K, generator=g)
+    w1, b1 = torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g) * 0.1
+    w2, b2 = torch.randn(N, N, generator=g) / N ** 0.5, torch.randn(N, generator=g) * 0.1
+    dv = lambda t: t.to(device)
+    csr = ops.csr_from_edge_index(dv(ei), n)
+    w1p, w2p = ops.pack_weight_h3(dv(w1.t().contiguous())), ops.pack_weight_h3(dv(w2.t().contiguous()))
+    wide = ops.SpRows(n, 4 * N, device)
+    y = ops.gin_layer_h3(csr, dv(x), w1p, dv(b1), w2p, dv(b2), N, eps=0.1, act="relu", out_sp=wide.cols(0, N))
+    ref = oracle.apply_act(oracle.gin_conv(x.double(), ei, w1.double(), b1.double(), w2.double(), b2.double(), "relu", eps=0.1),
+                           "relu", None)
+    assert max_err(y, ref) < TOL
+    assert _row_rel(ops.join_rows_sp(wide.cols(0, N)), y.cpu()) < 2.0 ** -21
+
+
+@pytest.mark.parametrize("d,shape,dataset,edge_types,pairs", [(256, "drugcombo", "drugcombo", 2, 260), (512, "atoms40", "drugbank", 1, 120)])
+def test_gmn_model_with_sp_pipeline_forced(device, d, shape, dataset, edge_types, pairs):
+    """whole lower_level_gmn model (GIN + GMNPropagator x3 + readout + head) with the sp pipeline forced on at a size
+    the oracle finishes in seconds: every activation against fp64; d=512 takes the unfused GIN path, so x is
+    split by the streaming pass instead of the layer kernel"""
+    from test_gpu_configs import _gmn_model_vs_oracle
+    import blgnn.config as cfg
+    orig = cfg.make_flags
+
+    def forced(*a, **k):
+        k.setdefault("gmn_sp", "force")
+        return orig(*a, **k)
+
+    blgnn.make_flags = forced
+    try:
+        preds = _gmn_model_vs_oracle(device, d, 120, 1500, pairs, 61 + d, dataset, edge_types, shape)
+    finally:
+        blgnn.make_flags = orig
+    assert preds.shape[0] == pairs
