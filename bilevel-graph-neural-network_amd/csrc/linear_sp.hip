@@ -55,6 +55,9 @@ constexpr int SP_NPAR = 5;                         // bias, rowvec_w, bn scale, 
 constexpr int SP_LDS = SP_OSTG + SP_NPAR * SP_BN * 4 + SP_BM * 4;
 static_assert(SP_OSTG >= 2 * SP_STAGE, "staging area must cover the operand stages");
 
+#ifdef SP_STAMP
+__device__ unsigned long long g_sp_stamps[8];      // diagnostics: shader cycles / 100 MHz ticks around the main loop
+#endif
 #ifndef SP_X_AUX
 #define SP_X_AUX 0
 #endif
@@ -154,6 +157,18 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
     const int m0 = (tile / nb) * SP_BM, cb = tile % nb, n0 = cb * SP_BN;
     const int KS = P.K / SP_BK;
 
+#ifdef SP_STAGGER
+    // Tiles take the same time on every CU, so all 256 workgroups of a round reach their epilogue together and the
+    // round's 64 MB of results leave in one burst at the HBM write rate (measured: 28 k of a tile's 142 k cycles)
+    // while HBM idles during the main loops.  Spread the FIRST round's starts over one tile time (32 phases of the
+    // workgroup's index inside its XCD); later rounds inherit the offsets.
+    if (blockIdx.x < 256 && gridDim.x >= 512) {
+        const int phase = (blockIdx.x >> 3) & 31;
+        const int naps = phase * (KS * 112 + 400) / 512;          // x 64 x 8 cycles each: phase / 32 of ~ (3.6 k KS + 13 k) cycles
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
+
     // ---- LDS-DMA plan: per K step this wave brings 32 X rows and 32 W columns (4 + 4 pieces of 1 KB) ----------
     // piece i of X: rows 32 wid + 8 i + (lane >> 3), LDS slot lane & 7 <- global chunk slot ^ ((row >> 1) & 7).
     // Buffer addressing: wave-uniform parts (tile base, row group, K step) ride in the resource / the scalar
@@ -252,6 +267,13 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
     asm volatile("" : "+v"(winv));
     lds_barrier();
 
+#ifdef SP_STAMP
+    const bool stamp_on = blockIdx.x == gridDim.x / 2 + 3 && tid == 0;
+    if (stamp_on) { g_sp_stamps[0] = __builtin_amdgcn_s_memtime(); g_sp_stamps[1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+#ifdef SP_PRIO
+    if (wid >= 4) __builtin_amdgcn_s_setprio(1);           // the younger half loses VALU/issue arbitration otherwise
+#endif
     for (int ks = 0; ks < KS; ++ks) {
         const char *cur = smem + (ks & 1) * SP_STAGE;
 #ifndef SP_KNOCK_DMA
@@ -311,6 +333,12 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
         lds_barrier();                                      // stage ks & 1 fully read, stage (ks + 1) & 1 complete
     }
 
+#ifdef SP_STAMP
+    if (stamp_on) { g_sp_stamps[2] = __builtin_amdgcn_s_memtime(); g_sp_stamps[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+#ifdef SP_PRIO
+    if (wid >= 4) __builtin_amdgcn_s_setprio(0);
+#endif
     // park the epilogue parameters behind the staging tiles
     if (tid < SP_BN) {
 #pragma unroll
@@ -423,6 +451,331 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
             }
         }
     }
+#ifdef SP_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (stamp_on) { g_sp_stamps[4] = __builtin_amdgcn_s_memtime(); g_sp_stamps[5] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+}
+
+// The same GEMM on v_mfma_f32_16x16x32_f16: one MFMA per K step of 32 and 16 x 16 block (96 per wave and step, 16 cycles
+// each: the cycles of the 32 x 32 x 16 form).  Why: the loop is power-limited (in-kernel clock 1.5 GHz with both operand
+// streams running, 1.9 GHz without them, 2.4 GHz without the MFMAs), and the 16 x 16 shape holds a higher clock at equal
+// cycles per flop.  A lane owns FOUR rows (one per 16-row block) and, per accumulator, four consecutive columns.
+template <bool GEN>
+__global__ void __launch_bounds__(512, 2) k_linear_sp16(const LinearSpArgs P) {
+    extern __shared__ float4 sp_smem[];
+    char *smem = reinterpret_cast<char *>(sp_smem);
+    float *cpar = reinterpret_cast<float *>(smem + SP_OSTG);                  // [SP_NPAR][256]   (epilogue only)
+    unsigned *rowmax = reinterpret_cast<unsigned *>(cpar + SP_NPAR * SP_BN);   // [256] bits of max |y| per row
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform by construction: keep it scalar
+    const int nb = P.N / SP_BN;
+    int tile;
+    {   // blocks b, b + 8, ... share an XCD: give each XCD a contiguous run of tiles (row-panel major), so the
+        // column blocks of one row panel read it from the same L2
+        const int nblk = gridDim.x, b = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = b & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int m0 = (tile / nb) * SP_BM, cb = tile % nb, n0 = cb * SP_BN;
+    const int KS = P.K / SP_BK;
+
+#ifdef SP_STAGGER
+    // Tiles take the same time on every CU, so all 256 workgroups of a round reach their epilogue together and the
+    // round's 64 MB of results leave in one burst at the HBM write rate (measured: 28 k of a tile's 142 k cycles)
+    // while HBM idles during the main loops.  Spread the FIRST round's starts over one tile time (32 phases of the
+    // workgroup's index inside its XCD); later rounds inherit the offsets.
+    if (blockIdx.x < 256 && gridDim.x >= 512) {
+        const int phase = (blockIdx.x >> 3) & 31;
+        const int naps = phase * (KS * 112 + 400) / 512;          // x 64 x 8 cycles each: phase / 32 of ~ (3.6 k KS + 13 k) cycles
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
+
+    // ---- LDS-DMA plan: per K step this wave brings 32 X rows and 32 W columns (4 + 4 pieces of 1 KB) ----------
+    // piece i of X: rows 32 wid + 8 i + (lane >> 3), LDS slot lane & 7 <- global chunk slot ^ ((row >> 1) & 7).
+    // Buffer addressing: wave-uniform parts (tile base, row group, K step) ride in the resource / the scalar
+    // offset, the lane's part is one 32-bit register for even and one for odd pieces; rows past M lie beyond
+    // num_records and arrive as zeros.
+    const int64_t rowb = P.ldxs * 2;
+    const int rows_in = min(SP_BM, P.M - m0);
+    const __amdgpu_buffer_rsrc_t RX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(P.xs) + (int64_t)m0 * rowb), 0,
+        (int)((int64_t)(rows_in - 1) * rowb + (int64_t)P.K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t RW = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(P.wp + HHDR) + (size_t)cb * KS * SP_WST), 0,
+        KS * SP_WST, 0x00020000);
+    const int xv0 = (lane >> 3) * (int)rowb + (((lane & 7) ^ (lane >> 4)) << 4);
+    const int xv1 = (lane >> 3) * (int)rowb + (((lane & 7) ^ (lane >> 4) ^ 4) << 4);
+    const int wv = lane * 16;
+    const int xs0 = 32 * wid * (int)rowb;
+    auto dma_piece = [&](int ks, int p) {                   // piece p of K step ks: 0..3 X rows, 4..7 W columns
+        char *st = smem + (ks & 1) * SP_STAGE;
+        if (p < 4) {
+#ifndef SP_KNOCK_XDMA
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(RX, (sp_lds_void *)(st + (32 * wid + 8 * p) * SP_ROWB), 16,
+                                                     (p & 1) ? xv1 : xv0, xs0 + 8 * p * (int)rowb + ks * SP_ROWB, 0, SP_X_AUX);
+#endif
+        } else {
+#ifndef SP_KNOCK_WDMA
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(RW, (sp_lds_void *)(st + SP_XST + wid * 4096 + (p - 4) * 1024), 16, wv,
+                                                     ks * SP_WST + wid * 4096 + (p - 4) * 1024, 0, 0);
+#endif
+        }
+    };
+    auto dma = [&](int ks) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) dma_piece(ks, p);
+    };
+
+    // ---- this wave's 64 x 128 outputs: row blocks im (4 x 16 rows), column blocks jn (8 x 16 columns) -----------
+    const int r16 = lane & 15, kg = lane >> 4, wm = wid >> 1, wn = wid & 1;
+    const int sw = (r16 >> 1) & 7;                               // 16-row offsets keep (row >> 1) & 7
+    const int xrow = (wm * 64 + r16) * SP_ROWB, wrow = SP_XST + (wn * 128 + r16) * SP_ROWB;
+    const int c1 = (kg ^ sw) << 4, c2 = ((4 + kg) ^ sw) << 4;   // this lane's 8 k of the high / low piece
+    f32x4v acc[4][8];
+#pragma unroll
+    for (int im = 0; im < 4; ++im)
+#pragma unroll
+        for (int jn = 0; jn < 8; ++jn) acc[im][jn] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    dma(0);                                                 // K step 0 requested before anything else
+
+    // epilogue parameters of this thread's column: fetched now (behind the ring prologue's requests), parked in
+    // registers (the ring owns all of LDS), written to LDS after the last K step
+    float par[SP_NPAR] = {0.f, 0.f, 1.f, 0.f, 0.f};
+    if (tid < SP_BN) {
+        const int n = n0 + tid;
+        if (P.epi.bias) par[0] = P.epi.bias[n];
+        if (P.rowvec_w) par[1] = P.rowvec_w[n];
+        if (P.epi.bn_scale) par[2] = P.epi.bn_scale[n];
+        if (P.epi.bn_scale && P.epi.bn_shift) par[3] = P.epi.bn_shift[n];
+        if (P.epi.act == BLGNN_ACT_PRELU && P.epi.act_param) par[4] = P.epi.act_param[n];
+    }
+
+    // scale bookkeeping per owned row: the blocks' inverse scales are powers of two; their biased exponent fields
+    // (8 bits each, K <= 2048: at most 8 blocks) are packed into one 64-bit word per row, so the main loop issues
+    // no vector-memory instruction but the ring's -- a load the loop waited on would drain the ring
+    const int KB = P.K / SP_BLOCK;
+    unsigned long long epack[4];
+    int eiu[4], eimax[4];
+    float rv[4];
+#pragma unroll
+    for (int im = 0; im < 4; ++im) {
+        const int mr = m0 + wm * 64 + 16 * im + r16;
+        const int m = min(mr, P.M - 1);
+        const float *xep = P.xe + (int64_t)m * P.ldxe;
+        // unconditional clamped loads (a guarded load becomes a branch with its own full wait); blocks past KB
+        // repeat the last one and are never consulted
+        float ev[8];
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) ev[kb] = xep[kb < KB ? kb : KB - 1];
+        unsigned long long pk = 0;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) pk |= (unsigned long long)(__float_as_uint(ev[kb]) >> 23) << (8 * kb);
+        epack[im] = pk;
+        eiu[im] = eimax[im] = (int)(pk & 0xffu);
+        rv[im] = P.rowvec ? P.rowvec[m] : 0.f;
+    }
+    float winv = *reinterpret_cast<const float *>(P.wp);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // K step 0 has landed (and the plain loads above)
+    // the compiler does not see that wait: pin every loaded value here, or it places its own full wait at the
+    // first use -- inside the loop (draining the ring at every block boundary) or in front of the epilogue
+#pragma unroll
+    for (int im = 0; im < 4; ++im) {
+        unsigned lo = (unsigned)epack[im], hi = (unsigned)(epack[im] >> 32);
+        asm volatile("" : "+v"(lo), "+v"(hi), "+v"(rv[im]));
+        epack[im] = ((unsigned long long)hi << 32) | lo;
+    }
+#pragma unroll
+    for (int j = 0; j < SP_NPAR; ++j) asm volatile("" : "+v"(par[j]));
+    asm volatile("" : "+v"(winv));
+    lds_barrier();
+
+#ifdef SP_STAMP
+    const bool stamp_on = blockIdx.x == gridDim.x / 2 + 3 && tid == 0;
+    if (stamp_on) { g_sp_stamps[0] = __builtin_amdgcn_s_memtime(); g_sp_stamps[1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+#ifdef SP_PRIO
+    if (wid >= 4) __builtin_amdgcn_s_setprio(1);           // the younger half loses VALU/issue arbitration otherwise
+#endif
+    for (int ks = 0; ks < KS; ++ks) {
+        const char *cur = smem + (ks & 1) * SP_STAGE;
+#ifndef SP_KNOCK_DMA
+        if (ks + 1 < KS) dma(ks + 1);                  // the other stage: last read during step ks - 1
+#endif
+        if ((ks & 7) == 0 && ks > 0) {
+            // block boundary: re-express the accumulators in the next block's unit
+            const int kb = ks >> 3;
+#pragma unroll
+            for (int im = 0; im < 4; ++im) {
+                const int ei = (int)((epack[im] >> (8 * kb)) & 0xffu);
+                eimax[im] = max(eimax[im], ei);
+                const int enew = max(ei, eimax[im] - 40);
+                const int d = max(eiu[im] - enew, -126);
+                eiu[im] = enew;
+                const float ratio = __uint_as_float((unsigned)(127 + d) << 23);
+#pragma unroll
+                for (int jn = 0; jn < 8; ++jn) acc[im][jn] *= ratio;
+            }
+        }
+        f16x8 a[8][2], b[4][2];
+#pragma unroll
+        for (int im = 0; im < 4; ++im) {
+            b[im][0] = *reinterpret_cast<const f16x8 *>(cur + xrow + c1 + 16 * im * SP_ROWB);
+            b[im][1] = *reinterpret_cast<const f16x8 *>(cur + xrow + c2 + 16 * im * SP_ROWB);
+        }
+#pragma unroll
+        for (int jn = 0; jn < 8; ++jn) {
+            a[jn][0] = *reinterpret_cast<const f16x8 *>(cur + wrow + c1 + 16 * jn * SP_ROWB);
+            a[jn][1] = *reinterpret_cast<const f16x8 *>(cur + wrow + c2 + 16 * jn * SP_ROWB);
+        }
+        // column-block major, the small terms first: a W fragment pair serves four row blocks and retires.
+        // (Tried: all 24 fragment reads first and the next step's eight LDS-DMA issues spread between the first MFMA
+        // groups instead of at the head of the step -- 4 900 instead of 3 830 cycles per step: the compiler orders
+        // LDS-DMA against ds_read and waits for every read in front of the first request.)
+#ifndef SP_KNOCK_MFMA
+#pragma unroll
+        for (int jn = 0; jn < 8; ++jn) {
+#pragma unroll
+            for (int im = 0; im < 4; ++im)
+                acc[im][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[jn][1], b[im][0], acc[im][jn], 0, 0, 0);
+#pragma unroll
+            for (int im = 0; im < 4; ++im)
+                acc[im][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[jn][0], b[im][1], acc[im][jn], 0, 0, 0);
+#pragma unroll
+            for (int im = 0; im < 4; ++im)
+                acc[im][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[jn][0], b[im][0], acc[im][jn], 0, 0, 0);
+        }
+#else
+        acc[0][0][0] += (float)a[0][0][0] + (float)b[0][0][0];
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of step ks + 1 have landed
+        lds_barrier();                                      // stage ks & 1 fully read, stage (ks + 1) & 1 complete
+    }
+
+#ifdef SP_STAMP
+    if (stamp_on) { g_sp_stamps[2] = __builtin_amdgcn_s_memtime(); g_sp_stamps[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+#ifdef SP_PRIO
+    if (wid >= 4) __builtin_amdgcn_s_setprio(0);
+#endif
+    // park the epilogue parameters behind the staging tiles
+    if (tid < SP_BN) {
+#pragma unroll
+        for (int j = 0; j < SP_NPAR; ++j) cpar[j * SP_BN + tid] = par[j];
+        rowmax[tid] = 0u;
+    }
+    lds_barrier();
+
+    // ================================================ epilogue ================================================
+    // lane (r16, kg) of block (im, jn) holds row 16 im + r16, columns 16 jn + 4 kg + (0..3)
+    const int act = P.epi.act;
+    const bool relu = act == BLGNN_ACT_RELU;                   // GEN = false: relu or identity
+    float rsc[4];
+#pragma unroll
+    for (int im = 0; im < 4; ++im) rsc[im] = __uint_as_float((unsigned)eiu[im] << 23) * winv;
+    // straight-line: the staged parameters hold neutral values where the caller passed none (scale 1, shift 0,
+    // rank-1 factor 0); row blocks innermost, so a column group's parameters are read once
+#pragma unroll
+    for (int jn = 0; jn < 8; ++jn) {
+        const int nl = wn * 128 + 16 * jn + 4 * kg;
+        const float4 b4 = *reinterpret_cast<const float4 *>(cpar + nl);
+        const float4 w4 = *reinterpret_cast<const float4 *>(cpar + SP_BN + nl);
+        const float4 s4 = *reinterpret_cast<const float4 *>(cpar + 2 * SP_BN + nl);
+        const float4 t4 = *reinterpret_cast<const float4 *>(cpar + 3 * SP_BN + nl);
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
+        const float sc[4] = {s4.x, s4.y, s4.z, s4.w}, sh[4] = {t4.x, t4.y, t4.z, t4.w};
+        float sl[4] = {0.f, 0.f, 0.f, 0.f};
+        if (GEN) {
+            const float4 p4 = *reinterpret_cast<const float4 *>(cpar + 4 * SP_BN + nl);
+            sl[0] = p4.x; sl[1] = p4.y; sl[2] = p4.z; sl[3] = p4.w;
+        }
+#pragma unroll
+        for (int im = 0; im < 4; ++im)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = acc[im][jn][q] * rsc[im];
+                v = fmaf(rv[im], ww[q], v + bb[q]);
+                if (GEN) v = apply_act(v, act, sl[q]);
+                else v = (relu && !(v > 0.f)) ? 0.f : v;
+                acc[im][jn][q] = fmaf(v, sc[q], sh[q]);
+            }
+    }
+    // every wave passed the barrier that ended the last K step: the operand stages are free.  Wave-private
+    // staging tile of 32 rows x 128 columns (LDS operations of one wave complete in order: no barrier between its
+    // writes and reads): row blocks 2 ib and 2 ib + 1 per pass.
+    char *stg = smem + wid * SP_OWAVE;
+    if (P.y) {
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int jn = 0; jn < 8; ++jn) {
+                    const f32x4v v = acc[2 * ib + h][jn];
+                    *reinterpret_cast<float4 *>(stg + (16 * h + r16) * SP_OSTRIDE + (16 * jn + 4 * kg) * 4) =
+                        make_float4(v[0], v[1], v[2], v[3]);
+                }
+            const int mb = m0 + wm * 64 + 32 * ib;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int t = lane + 64 * it, row = t >> 5, c4 = t & 31;
+                const float4 v = *reinterpret_cast<const float4 *>(stg + row * SP_OSTRIDE + c4 * 16);
+                if (mb + row < P.M)
+                    *reinterpret_cast<float4 *>(P.y + (int64_t)(mb + row) * P.ldy + n0 + wn * 128 + c4 * 4) = v;
+            }
+        }
+    }
+    if (P.ys) {
+        // block scale = the row's largest magnitude over the tile's 256 columns (this wave + its column neighbour)
+#pragma unroll
+        for (int im = 0; im < 4; ++im) {
+            float mx = 0.f;
+#pragma unroll
+            for (int jn = 0; jn < 8; ++jn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mx = fmaxf(mx, fabsf(acc[im][jn][q]));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+            if (kg == 0) atomicMax(rowmax + wm * 64 + 16 * im + r16, __float_as_uint(mx));
+        }
+        lds_barrier();
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int im = 2 * ib + h;
+                float s, inv;
+                pow2_scale(__uint_as_float(rowmax[wm * 64 + 16 * im + r16]), s, inv);
+                const int m = m0 + wm * 64 + 16 * im + r16;
+                if (wn == 0 && kg == 0 && m < P.M) P.ye[(int64_t)m * P.ldye + (n0 >> 8)] = inv;
+#pragma unroll
+                for (int jn = 0; jn < 8; ++jn) {
+                    const f32x4v v = acc[im][jn] * s;
+                    const f16x4 h1 = __builtin_convertvector(v, f16x4);
+                    const f16x4 h2 = __builtin_convertvector(v - __builtin_convertvector(h1, f32x4v), f16x4);
+                    // columns 16 jn + 4 kg .. + 3 of the wave's 128: chunk jn >> 1, position (jn & 1) * 16 + 4 kg
+                    char *dst = stg + (16 * h + r16) * SP_OSTRIDE + (jn >> 1) * 128 + ((jn & 1) * 16 + 4 * kg) * 2;
+                    *reinterpret_cast<f16x4 *>(dst) = h1;
+                    *reinterpret_cast<f16x4 *>(dst + 64) = h2;
+                }
+            }
+            const int mb = m0 + wm * 64 + 32 * ib;
+            char *yrow = reinterpret_cast<char *>(P.ys) + ((n0 + wn * 128) >> 5) * 128;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int t = lane + 64 * it, row = t >> 5, pc = t & 31;
+                const float4 v = *reinterpret_cast<const float4 *>(stg + row * SP_OSTRIDE + pc * 16);
+                if (mb + row < P.M)
+                    *reinterpret_cast<float4 *>(yrow + (int64_t)(mb + row) * P.ldys * 2 + pc * 16) = v;
+            }
+        }
+    }
+#ifdef SP_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (stamp_on) { g_sp_stamps[4] = __builtin_amdgcn_s_memtime(); g_sp_stamps[5] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 template <bool GEN>
@@ -435,6 +788,19 @@ static int launch_linear_sp_t(const LinearSpArgs &P, hipStream_t s) {
         declared = true;
     }
     const int64_t blocks = (int64_t)((P.M + SP_BM - 1) / SP_BM) * (P.N / SP_BN);
+    // default: the 16 x 16 x 32 form (3-4 % faster: higher sustained clock); BLGNN_SP_MFMA16=0 pins the 32 x 32 x 16 kernel
+    static const bool m16 = [] { const char *e = getenv("BLGNN_SP_MFMA16"); return !(e && e[0] == '0'); }();
+    if (m16) {
+        static bool declared16 = false;
+        if (!declared16) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_sp16<GEN>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS) != hipSuccess)
+                return fail(BLGNN_ERR_LAUNCH, "linear_sp: cannot raise the dynamic LDS limit to %d bytes", SP_LDS);
+            declared16 = true;
+        }
+        hipLaunchKernelGGL(k_linear_sp16<GEN>, dim3((unsigned)blocks), dim3(512), SP_LDS, s, P);
+        return launch_status("linear_sp");
+    }
     hipLaunchKernelGGL(k_linear_sp<GEN>, dim3((unsigned)blocks), dim3(512), SP_LDS, s, P);
     return launch_status("linear_sp");
 }
