@@ -78,6 +78,7 @@ class _GatConv(torch.autograd.Function):
     def forward(ctx, x, weight, att, bias, csr, group, slope, act):
         _check_act(act)
         x, weight, att = x.detach(), weight.detach(), att.detach()
+        csr.require_symmetric("GATConv backward")
         y, h, sc, stats = ops.gat_forward_saved(csr, x, weight, att, bias.detach(), group, slope, act)
         ctx.csr, ctx.group, ctx.slope, ctx.act = csr, group, slope, act
         ctx.save_for_backward(x, weight, att, h, sc, stats, y)
@@ -113,6 +114,7 @@ class _GcnConv(torch.autograd.Function):
     def forward(ctx, x, weight, bias, csr, act):
         _check_act(act)
         x, weight = x.detach(), weight.detach()
+        csr.require_symmetric("GCNConv backward")
         y = ops.gcn_conv(csr, x, weight, bias.detach(), None, act=act)
         ctx.csr, ctx.act = csr, act
         ctx.save_for_backward(x, weight, y)
@@ -143,6 +145,8 @@ class _MultiEdgeGat(torch.autograd.Function):
         _check_act(act)
         x = x.detach()
         K = len(csrs)
+        for c in csrs:
+            c.require_symmetric("multi-edge GAT backward")
         saved, y = [], None
         for k in range(K):
             w, a, b = (p.detach() for p in params[3 * k:3 * k + 3])
@@ -187,6 +191,7 @@ class _SpmmSum(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, csr, self_coef):
+        csr.require_symmetric("GIN aggregation backward")
         ctx.csr, ctx.self_coef = csr, self_coef
         return ops.spmm_sum(csr, x.detach(), self_coef=self_coef, skip_self=True)
 
@@ -282,6 +287,7 @@ class _EdgeReluSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p, q, csr):
         p, q = p.detach().contiguous(), q.detach().contiguous()
+        csr.require_symmetric("GMN message backward")
         ctx.csr = csr
         ctx.save_for_backward(p, q)
         return ops.edge_relu_sum(csr, p, q)

@@ -261,6 +261,9 @@ class BiLevelEngine(object):
         if g.shape[0] != self.B:
             raise ValueError("blgnn: this engine scores %d pairs per step, got %d" % (self.B, g.shape[0]))
         if self._row_lut is not None:
+            # bounds first: a negative id would wrap around under numpy indexing and score another drug's row
+            if ((g < 0) | (g >= self._row_lut.size)).any():
+                raise KeyError("unknown graph id in pair batch")
             rows = self._row_lut[g]
             if (rows < 0).any():
                 raise KeyError("unknown graph id in pair batch")

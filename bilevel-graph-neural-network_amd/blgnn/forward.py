@@ -40,6 +40,11 @@ def get_initial_embd(train_data, model, chunk_pairs=None, cached_batches=None):
                    for i in range(0, len(allp), step)]
         if cached_batches is not None:
             cached_batches.extend(batches)
+    # a sweep starts from values, not from the previous sweep's autograd graph: detach once here, so that inside
+    # the sweep every chunk's pooled rows stay attached (layers_aggregation.py: NodeAggregation.forward)
+    graph = getattr(train_data.dataset, "interaction_combo_nxgraph", None)
+    if graph is not None and isinstance(getattr(graph, "init_x", None), torch.Tensor) and graph.init_x.requires_grad:
+        graph.init_x = graph.init_x.detach()
     out = [model(b) for b in batches]
     return out[0] if len(out) == 1 else torch.cat(out, dim=0)
 

@@ -68,7 +68,12 @@ def load_drugcombo_pairs_csv(path, name_to_gid):
 
 def _filter(gids, sizes_e, pairs, labels):
     """load_raw_data.py:142-196: drugs need a structure with >= 1 bond and must occur in the pair list;
-    a pair needs both drugs; one entry per unordered pair (the first label seen wins)."""
+    a pair needs both drugs; one entry per unordered pair (the first label seen wins).
+    Deviation (parity unpinned: the klepto name -> gid table the reference's loader needs is not in the checkout):
+    the reference's get_graph_pairs keeps a SET of edge types per unordered pair and lists the pair in every one
+    of those edge-type graphs (load_raw_data.py:142-166); its DrugCombo antagonism vote is looked up under the
+    unsorted name pair, so an 'A,B' line and a 'B,A' line can vote differently and such a pair sits in both
+    graphs there, in one (the first line's) here.  BiGNNDataset models one label per pair."""
     have = {g for g, ne in zip(gids, sizes_e) if ne > 0}
     in_pairs = set(pairs.reshape(-1).tolist())
     have &= in_pairs

@@ -139,7 +139,10 @@ class NodeAggregation(NodeAggregationPairs):
             if rng is not None and rng[0] == 0 and rng[1] == n_all:
                 graph.init_x = out                                  # the sweep covers every drug, in gs_map order
             else:
-                base = graph.init_x.detach() if isinstance(graph.init_x, torch.Tensor) and \
+                # a chunk of the sweep (src/train.py:48-72 always sweeps in several chunks and writes
+                # init_x[gs_map[gid]] = out[ind] in place): the rows earlier chunks wrote keep their autograd history --
+                # get_initial_embd detaches init_x ONCE, before the first chunk of a sweep
+                base = graph.init_x if isinstance(graph.init_x, torch.Tensor) and \
                     graph.init_x.shape[1] == out.shape[1] else \
                     torch.zeros((n_all, out.shape[1]), dtype=torch.float32, device=out.device)
                 graph.init_x = base.index_copy(0, rows.long(), out)     # row placement: data movement only

@@ -65,11 +65,32 @@ def _act(name):
 class CSR(object):
     """int32 CSR on the device: row = aggregation target, col = sources."""
 
-    __slots__ = ("rowptr", "col", "n", "nnz", "_deg")
+    __slots__ = ("rowptr", "col", "n", "nnz", "_deg", "_symmetric")
 
     def __init__(self, rowptr, col, n, nnz):
         self.rowptr, self.col, self.n, self.nnz = rowptr, col, int(n), int(nnz)
         self._deg = None
+        self._symmetric = None
+
+    def require_symmetric(self, what):
+        """The backward kernels of the aggregation operators reuse the forward CSR as its own transpose
+        (blgnn/autograd.py), which is only right for a symmetric edge set -- every graph of the reference path is
+        (model/layers_util.py:133 to_undirected), but a caller-supplied edge_index need not be.  Checked once per
+        CSR object on the device (index arithmetic, one host sync), cached; raises on an asymmetric graph instead
+        of returning silently wrong gradients."""
+        if self._symmetric is None:
+            if self.nnz == 0:
+                self._symmetric = True
+            else:
+                counts = (self.rowptr[1:] - self.rowptr[:-1]).long()
+                rows = torch.repeat_interleave(torch.arange(self.n, device=self.col.device), counts)
+                cols = self.col.long()
+                fwd = torch.sort(rows * self.n + cols).values
+                bwd = torch.sort(cols * self.n + rows).values
+                self._symmetric = bool(torch.equal(fwd, bwd))
+        if not self._symmetric:
+            raise ValueError("blgnn: %s needs a symmetric graph (edge (i, j) present iff (j, i) is): the backward "
+                             "pass reuses the forward CSR as its transpose" % what)
 
 
 def csr_from_edge_index(edge_index, num_nodes, symmetric=True):

@@ -286,6 +286,63 @@ def test_bignn_training_step_gradients(device, lower):
     assert checked >= 5 * {"gin": 6, "gat": 5, "gcn": 4}[lower] + 3 * 5 + 4
 
 
+def test_bignn_training_two_chunk_sweep_gradients(device):
+    """src/train.py:48-72 sweeps the molecules in chunks of FLAGS.batch_size pairs and writes every chunk's pooled
+    rows into init_x in place, so ALL chunks stay in the autograd graph (and train-mode BatchNorm takes per-chunk
+    statistics).  A two-chunk sweep here: loss and every parameter gradient against fp64 autograd on the oracle
+    run the same way -- a chunk whose rows were detached would show up as wrong lower-level gradients."""
+    from blgnn.forward import get_initial_embd, all_molecule_pairs
+    D = 64
+    ds = blgnn.make_synthetic(70, 500, seed=21, device=device)
+    flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin", higher_level_gnn_type="gat",
+                             D_lower=D, D_higher=D, device=device)
+    model, data = build(flags, ds, seed=22)
+    specs = layer_specs(flags)
+    rng = np.random.default_rng(4)
+    pairs = ds.pair_gids[rng.choice(len(ds.pair_gids), size=40, replace=False)]
+    allp = all_molecule_pairs(ds.gs_map.keys())
+    step = (len(allp) + 1) // 2
+    assert step < len(allp)
+    # ---- ours: two chunks, gradients through both
+    model.train()
+    get_initial_embd(data, model, chunk_pairs=step)
+    ds.init_interaction_graph_embds(device)
+    assert ds.interaction_combo_nxgraph.init_x.requires_grad
+    bd = blgnn.BatchData(pairs, ds, sampled_gids=np.unique(pairs), is_train=True, rng=np.random.default_rng(3))
+    model.use_layers = 'higher_layers'
+    loss = model(bd)
+    loss.backward()
+    # ---- oracle: the lower slice once per chunk (in-place init_x rows, as the reference), then the upper slice
+    n_lower = 1 + max(k for k, sp in enumerate(specs) if sp.startswith("NodeAggregation"))
+    sd = _oracle_state(model)
+    of = dict(oracle_flags(flags, ds), train=True)
+    ids = torch.as_tensor(np.vectorize(ds.gs_map.get)(bd.batch_gids))
+    init_x, plain = None, None
+    for i in range(0, len(allp), step):
+        chunk = blgnn.BatchData(allp[i:i + step], ds, is_train=False, ignore_pairs=True)
+        plain = plain_batch(chunk, ds, torch.float64, with_pairs=ids)
+        plain["init_x"] = init_x
+        oracle.run_layers(specs[:n_lower], sd, plain, of)
+        init_x = plain["init_x"]
+    acts = oracle.run_layers(specs[n_lower:], sd, plain, of, first=n_lower, x0=init_x)
+    ref_loss = torch.nn.functional.binary_cross_entropy(acts[-1].view(-1), bd.true_labels().cpu().double())
+    ref_loss.backward()
+    assert max_err(loss, ref_loss) < TOL
+    checked = 0
+    for name, p in model.named_parameters():
+        if name not in sd or not name.startswith("layers."):
+            continue
+        assert p.grad is not None, name
+        assert max_err(p.grad, sd[name].grad) < TOL, name
+        checked += 1
+    assert checked >= 5 * 6 + 3 * 5 + 4
+    # a second sweep starts from values: it must not chain onto the first sweep's (already freed) graph
+    get_initial_embd(data, model, chunk_pairs=step)
+    ds.init_interaction_graph_embds(device)
+    model.use_layers = 'higher_layers'
+    model(bd).backward()
+
+
 def test_drugcombo_bignn_training_gradients(device):
     """DrugCombo variant of the bi-level model: the interaction level sums one GATConv per edge type
     (NodeModelAggrByEdge('gat'), model/layers_meta.py:70,74-79) and the scorer emits one logit per label; gradients
