@@ -358,9 +358,9 @@ def _packed_weight(w_kn, kind="x6"):
 
 class SpRows:
     """An activation matrix [rows, cols] in the sp format of ``blgnn_linear_sp`` (include/blgnn.h, csrc/sp_common.hpp):
-    ``planes`` fp16 [rows, 2 * cols] (per 32-column chunk: 32 high pieces, then 32 low pieces) and ``scales`` fp32
-    [rows, cols / 256] (inverse power-of-two scale of every 256-column block) -- the same bytes as fp32, split once
-    by the producer.  ``cols(c0, c1)`` (multiples of 256) is a view: producers fill their slices independently."""
+    ``planes`` fp16 [rows, 2 * cols] (per 32-column chunk: 32 high pieces, then 32 low pieces) and ``scales`` uint8
+    [rows, cols / 256] (the power-of-two scale of every 256-column block as an exponent byte; rows padded to 8 bytes
+    so that a GEMM reads a row's exponents with one load) -- the same bytes as fp32, split once by the producer.  ``cols(c0, c1)`` (multiples of 256) is a view: producers fill their slices independently."""
 
     BLOCK = 256
 
@@ -369,7 +369,8 @@ class SpRows:
             if cols % self.BLOCK != 0:
                 raise ValueError("blgnn: sp matrices need a multiple of 256 columns (got %d)" % cols)
             planes = torch.empty((rows, 2 * cols), dtype=torch.float16, device=device)
-            scales = torch.empty((rows, cols // self.BLOCK), dtype=torch.float32, device=device)
+            nblk = cols // self.BLOCK
+            scales = torch.zeros((rows, (nblk + 7) // 8 * 8), dtype=torch.uint8, device=device)[:, :nblk]
         self.planes, self.scales = planes, scales
 
     @property
@@ -393,8 +394,8 @@ def _sp_args(sp, rows, cols):
     if tuple(sp.shape) != (rows, cols):
         raise ValueError("blgnn: sp matrix has shape %s, expected %s" % (tuple(sp.shape), (rows, cols)))
     pl, sc = sp.planes, sp.scales
-    if pl.dtype != torch.float16 or sc.dtype != torch.float32 or pl.stride(1) != 1 or sc.stride(1) != 1:
-        raise ValueError("blgnn: sp planes must be fp16 rows, scales fp32 rows")
+    if pl.dtype != torch.float16 or sc.dtype != torch.uint8 or pl.stride(1) != 1 or sc.stride(1) != 1:
+        raise ValueError("blgnn: sp planes must be fp16 rows, scales uint8 rows")
     require_device(pl, "sp planes")
     return pl.data_ptr(), pl.stride(0), sc.data_ptr(), sc.stride(0)
 

@@ -44,7 +44,7 @@ struct GatherArgs {
     float *amax;         // optional [n]: atomic max of the result row's magnitudes into it (k_gather only)
     _Float16 *ys;        // optional sp-format output (sp_common.hpp; k_gather with one wavefront per row, d % 256 == 0);
     int64_t ldys;        //   y itself may then be null
-    float *ye;
+    uint8_t *ye;         //   block scale exponents (one byte per 256 columns)
     int64_t ldye;
     // epilogue
     Epilogue epi;
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256) k_gather(const GatherArgs A) {
                 for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, WAVE));
                 float sc, inv;
                 pow2_scale(mx, sc, inv);
-                if (l == 0) A.ye[(int64_t)row * A.ldye + k] = inv;
+                if (l == 0) A.ye[(int64_t)row * A.ldye + k] = sp_exp_of(inv);
                 const f32x4v sv = {acc[k].x * sc, acc[k].y * sc, acc[k].z * sc, acc[k].w * sc};
                 sp_store4(A.ys + (int64_t)row * A.ldys + k * (2 * SP_BLOCK), 4 * l, sv);
             }
@@ -930,7 +930,7 @@ extern "C" int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col, in
 extern "C" int blgnn_edge_relu_sum(const int32_t *rowptr, const int32_t *col, int64_t nnz, const float *p,
                                    int64_t ldp, const float *q, int64_t ldq, float *y,
                                    int64_t ldy, int32_t n, int32_t d, float *row_amax, void *y_sp, int64_t ld_ysp,
-                                   float *y_spe, int64_t ld_yspe, void *stream) {
+                                   uint8_t *y_spe, int64_t ld_yspe, void *stream) {
     if (int rc = check_csr(rowptr, col, n, nnz, "edge_relu_sum")) return rc;
     BLGNN_CHECK_ARG(d >= 0 && (n == 0 || d == 0 || (p && q && (y || y_sp))), "edge_relu_sum: null pointer");
     BLGNN_CHECK_ARG(ldp >= d && ldq >= d && (!y || ldy >= d), "edge_relu_sum: leading dimension < d");

@@ -78,7 +78,7 @@ struct GinH3Args {
     int32_t pool_mean;                       // w = 1 / max(rows of the graph, 1), else 1
     float *y_amax;                           // optional [n]: max |y[i, :]| per row (row scale of a following f16x3 GEMM)
     _Float16 *ysp; int64_t ldysp;            // optional (N == 256): y also in the sp format (sp_common.hpp) ...
-    float *yspe; int64_t ldyspe;             //   ... with its inverse block scale per row, for blgnn_linear_sp
+    uint8_t *yspe; int64_t ldyspe;           //   ... with its block scale exponent per row, for blgnn_linear_sp
 };
 
 // columns 4 l .. 4 l + 3 of the one-hot row of an atom
@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
                 // the row is one 256-column scale block: the GMN propagator's GEMMs read it from here
                 float sc, inv;
                 pow2_scale(mx, sc, inv);
-                if (c4 == 0) A.yspe[(int64_t)row * A.ldyspe] = inv;
+                if (c4 == 0) A.yspe[(int64_t)row * A.ldyspe] = sp_exp_of(inv);
                 const f32x4v sv = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
                 sp_store4(A.ysp + (int64_t)row * A.ldysp, 4 * c4, sv);
             }
@@ -582,7 +582,7 @@ extern "C" int blgnn_gin_layer_h3(const int32_t *rowptr, const int32_t *col, int
                                   const float *act_param, const float *bn_scale, const float *bn_shift,
                                   float *y, int64_t ldy, const int32_t *row_graph, const int32_t *seg,
                                   float *pooled, int64_t ldp, int32_t pool_kind, float *y_row_amax, void *y_sp,
-                                  int64_t ld_ysp, float *y_spe, int64_t ld_yspe, void *stream) {
+                                  int64_t ld_ysp, uint8_t *y_spe, int64_t ld_yspe, void *stream) {
     BLGNN_CHECK_ARG(n >= 0 && K > 0 && N > 0 && nnz >= 0, "gin_layer_h3: bad sizes");
     BLGNN_CHECK_ARG(!y_sp || (N == SP_BLOCK && y_spe && ld_ysp >= 2 * SP_BLOCK && ld_ysp % 8 == 0 && aligned16(y_sp) && ld_yspe >= 1),
                     "gin_layer_h3: sp output needs N == 256 and 16-byte aligned planes");

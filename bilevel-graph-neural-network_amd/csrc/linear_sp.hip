@@ -33,11 +33,11 @@ namespace blgnn {
 
 struct LinearSpArgs {
     const _Float16 *xs; int64_t ldxs;      // sp planes of X: fp16 elements per row (2 K for a dense matrix)
-    const float *xe; int64_t ldxe;         // inverse block scales [M][K / 256]
+    const uint8_t *xe; int64_t ldxe;       // block scale exponents [M][K / 256] (8-byte aligned rows: ldxe % 8 == 0)
     const _Float16 *wp;                    // blgnn_pack_weight_sp image
     float *y; int64_t ldy;                 // fp32 output (nullable)
     _Float16 *ys; int64_t ldys;            // sp output (nullable) ...
-    float *ye; int64_t ldye;               // ... and its inverse block scales [M][N / 256]
+    uint8_t *ye; int64_t ldye;             // ... and its block scale exponents [M][N / 256]
     int32_t M, N, K;
     const float *rowvec, *rowvec_w;
     Epilogue epi;
@@ -103,7 +103,7 @@ __global__ void k_absmax_sp(const float *__restrict__ w, int64_t ldw, int K, int
 // ---- fp32 rows -> sp format (for producers that do not write it themselves): one wave per (row, block) ---------
 __global__ void __launch_bounds__(256) k_split_sp(const float *__restrict__ x, int64_t ldx, int M, int KB,
                                                   _Float16 *__restrict__ xs, int64_t ldxs,
-                                                  float *__restrict__ xe, int64_t ldxe) {
+                                                  uint8_t *__restrict__ xe, int64_t ldxe) {
     const int lane = threadIdx.x & 63;
     const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (unit >= (int64_t)M * KB) return;
@@ -113,20 +113,20 @@ __global__ void __launch_bounds__(256) k_split_sp(const float *__restrict__ x, i
     mx = group_max(mx, WAVE);
     float s, inv;
     pow2_scale(mx, s, inv);
-    if (lane == 0) xe[(int64_t)m * ldxe + kb] = inv;
+    if (lane == 0) xe[(int64_t)m * ldxe + kb] = sp_exp_of(inv);
     const f32x4v sv = {v.x * s, v.y * s, v.z * s, v.w * s};
     sp_store4(xs + (int64_t)m * ldxs + kb * (2 * SP_BLOCK), lane * 4, sv);
 }
 
 // ---- sp format -> fp32 rows (tests, and consumers outside the GEMM) ------------------------------------------
 __global__ void __launch_bounds__(256) k_join_sp(const _Float16 *__restrict__ xs, int64_t ldxs,
-                                                 const float *__restrict__ xe, int64_t ldxe, int M, int KB,
+                                                 const uint8_t *__restrict__ xe, int64_t ldxe, int M, int KB,
                                                  float *__restrict__ x, int64_t ldx) {
     const int lane = threadIdx.x & 63;
     const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (unit >= (int64_t)M * KB) return;
     const int m = (int)(unit / KB), kb = (int)(unit % KB);
-    const float inv = xe[(int64_t)m * ldxe + kb];
+    const float inv = sp_inv_of(xe[(int64_t)m * ldxe + kb]);
     const int col = lane * 4;
     const _Float16 *src = xs + (int64_t)m * ldxs + kb * (2 * SP_BLOCK) + (col >> 5) * 64 + (col & 31);
     const f16x4 h1 = *reinterpret_cast<const f16x4 *>(src), h2 = *reinterpret_cast<const f16x4 *>(src + 32);
@@ -238,15 +238,8 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib) {
         const int m = min(m0 + wm * 64 + 32 * ib + fi, P.M - 1);
-        const float *xep = P.xe + (int64_t)m * P.ldxe;
-        // unconditional clamped loads (a guarded load becomes a branch with its own full wait: eight dependent
-        // round trips per row block); blocks past KB repeat the last one and are never consulted
-        float ev[8];
-#pragma unroll
-        for (int kb = 0; kb < 8; ++kb) ev[kb] = xep[kb < KB ? kb : KB - 1];
-        unsigned long long pk = 0;
-#pragma unroll
-        for (int kb = 0; kb < 8; ++kb) pk |= (unsigned long long)(__float_as_uint(ev[kb]) >> 23) << (8 * kb);
+        // the row's block exponents: one 8-byte load (bytes past KB belong to other blocks and are never consulted)
+        const unsigned long long pk = *reinterpret_cast<const unsigned long long *>(P.xe + (int64_t)m * P.ldxe);
         epack[ib] = pk;
         eiu[ib] = eimax[ib] = (int)(pk & 0xffu);
         const int mr = m0 + wm * 64 + 32 * ib + fi;
@@ -427,7 +420,7 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
             float s, inv;
             pow2_scale(__uint_as_float(rowmax[wm * 64 + 32 * ib + fi]), s, inv);
             const int m = mrow0 + 32 * ib;
-            if (wn == 0 && fh == 0 && m < P.M) P.ye[(int64_t)m * P.ldye + (n0 >> 8)] = inv;
+            if (wn == 0 && fh == 0 && m < P.M) P.ye[(int64_t)m * P.ldye + (n0 >> 8)] = sp_exp_of(inv);
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
@@ -461,6 +454,10 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
 // each: the cycles of the 32 x 32 x 16 form).  Why: the loop is power-limited (in-kernel clock 1.5 GHz with both operand
 // streams running, 1.9 GHz without them, 2.4 GHz without the MFMAs), and the 16 x 16 shape holds a higher clock at equal
 // cycles per flop.  A lane owns FOUR rows (one per 16-row block) and, per accumulator, four consecutive columns.
+// (Tried and dropped: a persistent form -- one workgroup per CU walking its tiles, the next tile's first operand stage
+// and row parameters requested before the current tile's epilogue, 16-row staging passes out of the stage-1 region --
+// to hide the ~14 us of a tile's 90 that are neither main loop nor epilogue: 2 746 vs 2 591 us at K = N = 1024, 1 046 vs
+// 1 002 at K = 256: static tile assignment loses more than the hidden round trips gain.)
 template <bool GEN>
 __global__ void __launch_bounds__(512, 2) k_linear_sp16(const LinearSpArgs P) {
     extern __shared__ float4 sp_smem[];
@@ -564,15 +561,8 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp16(const LinearSpArgs P) {
     for (int im = 0; im < 4; ++im) {
         const int mr = m0 + wm * 64 + 16 * im + r16;
         const int m = min(mr, P.M - 1);
-        const float *xep = P.xe + (int64_t)m * P.ldxe;
-        // unconditional clamped loads (a guarded load becomes a branch with its own full wait); blocks past KB
-        // repeat the last one and are never consulted
-        float ev[8];
-#pragma unroll
-        for (int kb = 0; kb < 8; ++kb) ev[kb] = xep[kb < KB ? kb : KB - 1];
-        unsigned long long pk = 0;
-#pragma unroll
-        for (int kb = 0; kb < 8; ++kb) pk |= (unsigned long long)(__float_as_uint(ev[kb]) >> 23) << (8 * kb);
+        // the row's block exponents: one 8-byte load (bytes past KB belong to other blocks and are never consulted)
+        const unsigned long long pk = *reinterpret_cast<const unsigned long long *>(P.xe + (int64_t)m * P.ldxe);
         epack[im] = pk;
         eiu[im] = eimax[im] = (int)(pk & 0xffu);
         rv[im] = P.rowvec ? P.rowvec[m] : 0.f;
@@ -749,7 +739,7 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp16(const LinearSpArgs P) {
                 float s, inv;
                 pow2_scale(__uint_as_float(rowmax[wm * 64 + 16 * im + r16]), s, inv);
                 const int m = m0 + wm * 64 + 16 * im + r16;
-                if (wn == 0 && kg == 0 && m < P.M) P.ye[(int64_t)m * P.ldye + (n0 >> 8)] = inv;
+                if (wn == 0 && kg == 0 && m < P.M) P.ye[(int64_t)m * P.ldye + (n0 >> 8)] = sp_exp_of(inv);
 #pragma unroll
                 for (int jn = 0; jn < 8; ++jn) {
                     const f32x4v v = acc[im][jn] * s;
@@ -836,7 +826,7 @@ extern "C" int blgnn_pack_weight_sp(const float *w, int64_t ldw, int32_t K, int3
 }
 
 extern "C" int blgnn_split_rows_sp(const float *x, int64_t ldx, int32_t M, int32_t K, void *xs, int64_t ldxs,
-                                   float *xe, int64_t ldxe, void *stream) {
+                                   uint8_t *xe, int64_t ldxe, void *stream) {
     BLGNN_CHECK_ARG(M >= 0 && K > 0 && K % SP_BLOCK == 0, "split_rows_sp: K must be a positive multiple of 256");
     if (M == 0) return BLGNN_OK;
     BLGNN_CHECK_ARG(x && xs && xe && ldx >= K && ldxs >= 2 * (int64_t)K && ldxe >= K / SP_BLOCK, "split_rows_sp: bad args");
@@ -848,7 +838,7 @@ extern "C" int blgnn_split_rows_sp(const float *x, int64_t ldx, int32_t M, int32
     return launch_status("split_rows_sp");
 }
 
-extern "C" int blgnn_join_rows_sp(const void *xs, int64_t ldxs, const float *xe, int64_t ldxe, int32_t M, int32_t K,
+extern "C" int blgnn_join_rows_sp(const void *xs, int64_t ldxs, const uint8_t *xe, int64_t ldxe, int32_t M, int32_t K,
                                   float *x, int64_t ldx, void *stream) {
     BLGNN_CHECK_ARG(M >= 0 && K > 0 && K % SP_BLOCK == 0, "join_rows_sp: K must be a positive multiple of 256");
     if (M == 0) return BLGNN_OK;
@@ -861,8 +851,8 @@ extern "C" int blgnn_join_rows_sp(const void *xs, int64_t ldxs, const float *xe,
     return launch_status("join_rows_sp");
 }
 
-extern "C" int blgnn_linear_sp(const void *xs, int64_t ldxs, const float *xe, int64_t ldxe, const void *w_packed,
-                               float *y, int64_t ldy, void *ys, int64_t ldys, float *ye, int64_t ldye,
+extern "C" int blgnn_linear_sp(const void *xs, int64_t ldxs, const uint8_t *xe, int64_t ldxe, const void *w_packed,
+                               float *y, int64_t ldy, void *ys, int64_t ldys, uint8_t *ye, int64_t ldye,
                                int32_t M, int32_t N, int32_t K, const float *bias, const float *rowvec,
                                const float *rowvec_w, int32_t act, const float *act_param,
                                const float *bn_scale, const float *bn_shift, void *stream) {
@@ -874,6 +864,9 @@ extern "C" int blgnn_linear_sp(const void *xs, int64_t ldxs, const float *xe, in
     BLGNN_CHECK_ARG(xs && xe && w_packed && (y || ys), "linear_sp: null pointer");
     BLGNN_CHECK_ARG(ldxs >= 2 * (int64_t)K && ldxs % 8 == 0 && aligned16(xs) && ldxe >= K / SP_BLOCK,
                     "linear_sp: bad X planes (ldxs >= 2K, 16-byte aligned rows)");
+    BLGNN_CHECK_ARG(ldxe % 8 == 0 && (reinterpret_cast<uintptr_t>(xe) & 7u) == 0,
+                    "linear_sp: the X scale rows must be 8-byte aligned (ldxe %% 8 == 0: the kernel fetches a row's block "
+                    "exponents with one 8-byte load)");
     BLGNN_CHECK_ARG(aligned16(w_packed), "linear_sp: packed weights must be 16-byte aligned");
     BLGNN_CHECK_ARG(!y || (ldy >= N && ldy % 4 == 0 && aligned16(y)), "linear_sp: y must have 16-byte aligned rows");
     BLGNN_CHECK_ARG(!ys || (ye && ldys >= 2 * (int64_t)N && ldys % 8 == 0 && aligned16(ys) && ldye >= N / SP_BLOCK),

@@ -3,9 +3,11 @@
 // An fp32 activation matrix X[M, K] (K % 256 == 0) is kept as
 //   xs : fp16 [M][K / 32][64]   per row and 32-column chunk: 32 high pieces h1, then 32 low pieces h2 (128 B =
 //                               one cache line per (row, K step of the GEMM));
-//   xe : fp32 [M][K / 256]      inverse of the power-of-two scale of every (row, 256-column block):
-//                               x[m, k] = (h1 + h2) * xe[m][k / 256],  h1 = fp16(x * s), h2 = fp16(x * s - h1),
-//                               s = 1 / xe chosen so that the block's largest magnitude lies in [2^14, 2^15)
+//   xe : uint8 [M][K / 256]     the power-of-two scale of every (row, 256-column block), as the biased fp32
+//                               exponent field e of its inverse: x[m, k] = (h1 + h2) * 2^(e - 127),
+//                               h1 = fp16(x * s), h2 = fp16(x * s - h1), s = 2^(127 - e) chosen so that the
+//                               block's largest magnitude lies in [2^14, 2^15); one byte per block, so the GEMM
+//                               fetches the (up to eight) block scales of a row with ONE 8-byte load
 // -- the same 4 bytes per element as fp32, the same 22 significand bits as the in-kernel split of linear_h3.hip
 // (h3_common.hpp), but formed ONCE by the kernel that produces X (its epilogue sees whole 256-column blocks of
 // a row) instead of by every column block of every GEMM that reads X.  Block scales instead of one scale per
@@ -18,6 +20,10 @@ namespace blgnn {
 
 constexpr int SP_CHUNK = 32;              // columns per chunk
 constexpr int SP_BLOCK = 256;             // columns per scale block
+
+// exponent byte <-> inverse scale (a power of two: its fp32 bit pattern is the exponent field alone)
+__device__ __forceinline__ uint8_t sp_exp_of(float inv) { return (uint8_t)(__float_as_uint(inv) >> 23); }
+__device__ __forceinline__ float sp_inv_of(uint8_t e) { return __uint_as_float((unsigned)e << 23); }
 
 // lane-group helper for kernels whose lanes own 4 consecutive columns (float4) of a row: writes the two 8-byte
 // piece groups of those columns.  `col` = column inside the row (multiple of 4), v already scaled.

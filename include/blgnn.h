@@ -162,7 +162,7 @@ int blgnn_gin_layer_h3(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                        const float *act_param, const float *bn_scale,
                        const float *bn_shift, float *y, int64_t ldy, const int32_t *row_graph,
                        const int32_t *seg, float *pooled, int64_t ldp, int32_t pool_kind,
-                       float *y_row_amax, void *y_sp, int64_t ld_ysp, float *y_spe, int64_t ld_yspe, void *stream);
+                       float *y_row_amax, void *y_sp, int64_t ld_ysp, uint8_t *y_spe, int64_t ld_yspe, void *stream);
 
 /* blgnn_gin_layer_h3 for the FIRST lower layer with categorical input: instead of the one-hot rows
  * x[n, F_in] (utils/data/representation_node_feat.py:86-97: one block per attribute, one 1 per block)
@@ -280,7 +280,7 @@ int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col, int64_t nnz,
 int blgnn_edge_relu_sum(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                         const float *p, int64_t ldp, const float *q, int64_t ldq,
                         float *y, int64_t ldy, int32_t n, int32_t d, float *row_amax,
-                        void *y_sp, int64_t ld_ysp, float *y_spe, int64_t ld_yspe, void *stream);
+                        void *y_sp, int64_t ld_ysp, uint8_t *y_spe, int64_t ld_yspe, void *stream);
 /* row degree as float (for the deg_i * b2 term of the restructured message) */
 int blgnn_row_degree(const int32_t *rowptr, int32_t n, float *deg, void *stream);
 
@@ -365,8 +365,10 @@ int blgnn_linear_h3(const float *x, int64_t ldx, const float *row_amax, const vo
  * sp format of an activation matrix X[M, K], K % 256 == 0 (csrc/sp_common.hpp):
  *   xs: fp16, row m at xs + m * ldxs (ldxs >= 2 K elements, rows 16-byte aligned); per 32-column chunk c of a
  *       row 64 values: the 32 high pieces h1 of columns 32c..32c+31, then their 32 low pieces h2;
- *   xe: fp32 [M][K / 256] (row stride ldxe): x[m, k] = (h1 + h2) * xe[m][k / 256]; 1 / xe is the power of two
- *       that moves the block's largest magnitude into [2^14, 2^15).
+ *   xe: uint8 [M][K / 256] (row stride ldxe bytes): the block's power-of-two scale as the biased fp32 exponent e
+ *       of its inverse, x[m, k] = (h1 + h2) * 2^(e - 127); 2^(127 - e) moves the block's largest magnitude
+ *       into [2^14, 2^15).  A GEMM fetches a row's (<= 8) exponents with one 8-byte load: the X operand of
+ *       blgnn_linear_sp needs ldxe % 8 == 0 and an 8-byte aligned xe (allocate 8 bytes per row).
  * A column range that starts and ends on multiples of 256 is again an sp matrix (xs + 2 * c0, xe + c0 / 256):
  * producers write their slices of the f_node input [x | S | u] independently.
  *
@@ -379,11 +381,11 @@ int blgnn_linear_h3(const float *x, int64_t ldx, const float *row_amax, const vo
 int64_t blgnn_packed_weight_sp_elems(int32_t K, int32_t N);
 int blgnn_pack_weight_sp(const float *w, int64_t ldw, int32_t K, int32_t N, void *out, void *stream);
 int blgnn_split_rows_sp(const float *x, int64_t ldx, int32_t M, int32_t K, void *xs, int64_t ldxs,
-                        float *xe, int64_t ldxe, void *stream);
-int blgnn_join_rows_sp(const void *xs, int64_t ldxs, const float *xe, int64_t ldxe, int32_t M, int32_t K,
+                        uint8_t *xe, int64_t ldxe, void *stream);
+int blgnn_join_rows_sp(const void *xs, int64_t ldxs, const uint8_t *xe, int64_t ldxe, int32_t M, int32_t K,
                        float *x, int64_t ldx, void *stream);
-int blgnn_linear_sp(const void *xs, int64_t ldxs, const float *xe, int64_t ldxe, const void *w_packed,
-                    float *y, int64_t ldy, void *ys, int64_t ldys, float *ye, int64_t ldye,
+int blgnn_linear_sp(const void *xs, int64_t ldxs, const uint8_t *xe, int64_t ldxe, const void *w_packed,
+                    float *y, int64_t ldy, void *ys, int64_t ldys, uint8_t *ye, int64_t ldye,
                     int32_t M, int32_t N, int32_t K, const float *bias, const float *rowvec,
                     const float *rowvec_w, int32_t act, const float *act_param,
                     const float *bn_scale, const float *bn_shift, void *stream);
