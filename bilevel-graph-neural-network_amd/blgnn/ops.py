@@ -370,7 +370,7 @@ class SpRows:
                 raise ValueError("blgnn: sp matrices need a multiple of 256 columns (got %d)" % cols)
             planes = torch.empty((rows, 2 * cols), dtype=torch.float16, device=device)
             nblk = cols // self.BLOCK
-            scales = torch.zeros((rows, (nblk + 7) // 8 * 8), dtype=torch.uint8, device=device)[:, :nblk]
+            scales = torch.empty((rows, (nblk + 7) // 8 * 8), dtype=torch.uint8, device=device)[:, :nblk]
         self.planes, self.scales = planes, scales
 
     @property

@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256) k_gather(const GatherArgs A) {
                 pow2_scale(mx, sc, inv);
                 if (l == 0) A.ye[(int64_t)row * A.ldye + k] = sp_exp_of(inv);
                 const f32x4v sv = {acc[k].x * sc, acc[k].y * sc, acc[k].z * sc, acc[k].w * sc};
-                sp_store4(A.ys + (int64_t)row * A.ldys + k * (2 * SP_BLOCK), 4 * l, sv);
+                sp_store4_pair(A.ys + (int64_t)row * A.ldys + k * (2 * SP_BLOCK), 4 * l, sv, l);
             }
             if (!A.y) continue;
         }

@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
                 pow2_scale(mx, sc, inv);
                 if (c4 == 0) A.yspe[(int64_t)row * A.ldyspe] = sp_exp_of(inv);
                 const f32x4v sv = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
-                sp_store4(A.ysp + (int64_t)row * A.ldysp, 4 * c4, sv);
+                sp_store4_pair(A.ysp + (int64_t)row * A.ldysp, 4 * c4, sv, threadIdx.x);   // (row: uniform per wavefront)
             }
         }
     }

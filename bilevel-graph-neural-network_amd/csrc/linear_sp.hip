@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(256) k_split_sp(const float *__restrict__ x, i
     pow2_scale(mx, s, inv);
     if (lane == 0) xe[(int64_t)m * ldxe + kb] = sp_exp_of(inv);
     const f32x4v sv = {v.x * s, v.y * s, v.z * s, v.w * s};
-    sp_store4(xs + (int64_t)m * ldxs + kb * (2 * SP_BLOCK), lane * 4, sv);
+    sp_store4_pair(xs + (int64_t)m * ldxs + kb * (2 * SP_BLOCK), lane * 4, sv, lane);
 }
 
 // ---- sp format -> fp32 rows (tests, and consumers outside the GEMM) ------------------------------------------
