@@ -10,9 +10,9 @@
 // fp32 X tile to two fp16 images INSIDE the GEMM -- four of its eight waves do nothing else, every column block
 // of a row panel repeats the conversion, and its knock-outs show the operand streams (not the matrix cores)
 // setting the time.  Here the producer of X has already split it, so
-//   * both operand tiles of a K step arrive by LDS-DMA (global_load_lds_dwordx4: no registers, no conversion, no
-//     ds_write); the swizzle that makes the fragment reads conflict free is applied by choosing which 16-byte
-//     chunk of the 128-byte row segment each lane fetches;
+//   * both operand tiles of a K step arrive by LDS-DMA (buffer_load ... lds, 16 bytes per lane: no registers, no
+//     conversion, no ds_write); the swizzle that makes the fragment reads conflict free is applied by choosing
+//     which 16-byte chunk of the 128-byte row segment each lane fetches (SQ_LDS_BANK_CONFLICT = 0);
 //   * all eight waves issue MFMAs (two per SIMD, 64 x 128 outputs each), the tile is 256 x 256 at K step 32:
 //     64 KB of operands per 12.6 MFLOP-x3 instead of 48 KB per 6.3;
 //   * the row-magnitude passes (blgnn_row_absmax, atomic row maxima in epilogues) disappear: scales travel with
@@ -22,9 +22,26 @@
 // the blocks' scales but never exceeds 2^40 x the smallest scale seen (a block 2^40 below the row's largest
 // contributes < 2^-40 of the dot product whatever is done with it), so nothing overflows on zero blocks or on
 // rows spanning the whole fp32 range.
-// Operand roles: W fragments are the MFMA A operand and X fragments the B operand, so a lane owns ONE row m of a
-// 32 x 32 block (scale bookkeeping = one register per row block) and four consecutive columns per accumulator
-// quad (epilogue parameters and stores are float4 wide).
+// Operand roles: W fragments are the MFMA A operand and X fragments the B operand, so a lane owns ROWS (one per
+// 16-row block: scale bookkeeping = one register pair per row) and four consecutive columns per accumulator
+// (epilogue parameters and stores are float4 wide).
+//
+// What bounds it (in-kernel stamps + PMC, K = N = 1024, 478 k rows): power.  The main loop
+// runs 3 500-3 800 cycles per K step against 3 072 of MFMA issue, but at an in-kernel clock of 1.5-1.8 GHz (1.9-2.1
+// with the operand requests knocked out, 2.4 with the MFMAs knocked out).  Measured on the way here (us per launch,
+// K = N = 1024 / K = 256, N = 1024 / K = 1024, N = 256; linear_h3.hip: 3 590 / 1 335 / 1 200):
+//   v_mfma_f32_32x32x16_f16, float scales                     2 735 / 1 030 /   905   (1.5 GHz)
+//   v_mfma_f32_16x16x32_f16 (same cycles per flop, holds a higher clock)
+//                                                             2 630 / 1 017 /   880   (1.8 GHz)
+//   + block scales as exponent bytes (one 8-byte load per row) 2 591 / 1 002 /   860
+// Tried and dropped: a 5-slot ring at K step 16 (four steps in flight instead of one: 2 906 -- the operand streams
+// are throughput-, not latency-bound: 35 GB/s per CU whatever is in flight); column blocks in passes so that an
+// XCD's L2 holds 1 or 2 of the 4 weight slices (no change); non-temporal X loads (no change); padded row strides
+// (no change); staggered first-round starts to spread the epilogues' store bursts (2 790); static priority for
+// waves 4-7 (no change); the next step's LDS-DMA issues spread between the MFMA groups (4 900 cycles per step: the
+// compiler orders LDS-DMA against ds_read and waits for every fragment read first); a persistent form (one
+// workgroup per CU walking its tiles, next tile's first stage and row parameters requested before the epilogue:
+// 2 746 / 1 046 -- static tile assignment loses more than the hidden round trips gain).
 #include <cstdlib>
 #include "linear_common.hpp"
 #include "sp_common.hpp"
@@ -57,9 +74,6 @@ static_assert(SP_OSTG >= 2 * SP_STAGE, "staging area must cover the operand stag
 
 #ifdef SP_STAMP
 __device__ unsigned long long g_sp_stamps[8];      // diagnostics: shader cycles / 100 MHz ticks around the main loop
-#endif
-#ifndef SP_X_AUX
-#define SP_X_AUX 0
 #endif
 typedef __attribute__((address_space(3))) void sp_lds_void;
 typedef __attribute__((address_space(1))) void sp_glb_void;
@@ -137,7 +151,14 @@ __global__ void __launch_bounds__(256) k_join_sp(const _Float16 *__restrict__ xs
 }
 
 // ---- the GEMM --------------------------------------------------------------------------------------------------
-// GEN = false: identity / relu only (the GMN GEMMs); GEN = true: every activation id (expf / tanhf inlined 128 times)
+// The same GEMM on v_mfma_f32_16x16x32_f16: one MFMA per K step of 32 and 16 x 16 block (96 per wave and step, 16 cycles
+// each: the cycles of the 32 x 32 x 16 form).  Why: the loop is power-limited (in-kernel clock 1.5 GHz with both operand
+// streams running, 1.9 GHz without them, 2.4 GHz without the MFMAs), and the 16 x 16 shape holds a higher clock at equal
+// cycles per flop.  A lane owns FOUR rows (one per 16-row block) and, per accumulator, four consecutive columns.
+// (Tried and dropped: a persistent form -- one workgroup per CU walking its tiles, the next tile's first operand stage
+// and row parameters requested before the current tile's epilogue, 16-row staging passes out of the stage-1 region --
+// to hide the ~14 us of a tile's 90 that are neither main loop nor epilogue: 2 746 vs 2 591 us at K = N = 1024, 1 046 vs
+// 1 002 at K = 256: static tile assignment loses more than the hidden round trips gain.)
 template <bool GEN>
 __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
     extern __shared__ float4 sp_smem[];
@@ -156,338 +177,6 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
     }
     const int m0 = (tile / nb) * SP_BM, cb = tile % nb, n0 = cb * SP_BN;
     const int KS = P.K / SP_BK;
-
-#ifdef SP_STAGGER
-    // Tiles take the same time on every CU, so all 256 workgroups of a round reach their epilogue together and the
-    // round's 64 MB of results leave in one burst at the HBM write rate (measured: 28 k of a tile's 142 k cycles)
-    // while HBM idles during the main loops.  Spread the FIRST round's starts over one tile time (32 phases of the
-    // workgroup's index inside its XCD); later rounds inherit the offsets.
-    if (blockIdx.x < 256 && gridDim.x >= 512) {
-        const int phase = (blockIdx.x >> 3) & 31;
-        const int naps = phase * (KS * 112 + 400) / 512;          // x 64 x 8 cycles each: phase / 32 of ~ (3.6 k KS + 13 k) cycles
-        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(8);
-    }
-#endif
-
-    // ---- LDS-DMA plan: per K step this wave brings 32 X rows and 32 W columns (4 + 4 pieces of 1 KB) ----------
-    // piece i of X: rows 32 wid + 8 i + (lane >> 3), LDS slot lane & 7 <- global chunk slot ^ ((row >> 1) & 7).
-    // Buffer addressing: wave-uniform parts (tile base, row group, K step) ride in the resource / the scalar
-    // offset, the lane's part is one 32-bit register for even and one for odd pieces; rows past M lie beyond
-    // num_records and arrive as zeros.
-    const int64_t rowb = P.ldxs * 2;
-    const int rows_in = min(SP_BM, P.M - m0);
-    const __amdgpu_buffer_rsrc_t RX = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(P.xs) + (int64_t)m0 * rowb), 0,
-        (int)((int64_t)(rows_in - 1) * rowb + (int64_t)P.K * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t RW = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(P.wp + HHDR) + (size_t)cb * KS * SP_WST), 0,
-        KS * SP_WST, 0x00020000);
-    const int xv0 = (lane >> 3) * (int)rowb + (((lane & 7) ^ (lane >> 4)) << 4);
-    const int xv1 = (lane >> 3) * (int)rowb + (((lane & 7) ^ (lane >> 4) ^ 4) << 4);
-    const int wv = lane * 16;
-    const int xs0 = 32 * wid * (int)rowb;
-    auto dma = [&](int ks) {
-        char *st = smem + (ks & 1) * SP_STAGE;
-#ifndef SP_KNOCK_XDMA
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(RX, (sp_lds_void *)(st + (32 * wid + 8 * i) * SP_ROWB), 16,
-                                                     (i & 1) ? xv1 : xv0, xs0 + 8 * i * (int)rowb + ks * SP_ROWB, 0, SP_X_AUX);
-#endif
-#ifndef SP_KNOCK_WDMA
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(RW, (sp_lds_void *)(st + SP_XST + wid * 4096 + i * 1024), 16, wv,
-                                                     ks * SP_WST + wid * 4096 + i * 1024, 0, 0);
-#endif
-    };
-
-    // ---- this wave's 64 x 128 outputs: row blocks ib (2), column blocks jb (4) ----------------------------------
-    const int fi = lane & 31, fh = lane >> 5, wm = wid >> 1, wn = wid & 1;
-    const int sw = (fi >> 1) & 7;
-    const int xrow = (wm * 64 + fi) * SP_ROWB, wrow = SP_XST + (wn * 128 + fi) * SP_ROWB;
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ib][jb][r] = 0.f;
-
-    dma(0);                                                 // K step 0 requested before anything else
-
-    // epilogue parameters of this thread's column: fetched now (behind the ring prologue's requests), parked in
-    // registers (the ring owns all of LDS), written to LDS after the last K step
-    float par[SP_NPAR] = {0.f, 0.f, 1.f, 0.f, 0.f};
-    if (tid < SP_BN) {
-        const int n = n0 + tid;
-        if (P.epi.bias) par[0] = P.epi.bias[n];
-        if (P.rowvec_w) par[1] = P.rowvec_w[n];
-        if (P.epi.bn_scale) par[2] = P.epi.bn_scale[n];
-        if (P.epi.bn_scale && P.epi.bn_shift) par[3] = P.epi.bn_shift[n];
-        if (P.epi.act == BLGNN_ACT_PRELU && P.epi.act_param) par[4] = P.epi.act_param[n];
-    }
-
-    // scale bookkeeping per owned row: the blocks' inverse scales are powers of two; their biased exponent fields
-    // (8 bits each, K <= 2048: at most 8 blocks) are packed into one 64-bit word per row, so the main loop issues
-    // no vector-memory instruction but the ring's -- a load the loop waited on would drain the ring
-    const int KB = P.K / SP_BLOCK;
-    unsigned long long epack[2];
-    int eiu[2], eimax[2];
-    float rv[2];
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib) {
-        const int m = min(m0 + wm * 64 + 32 * ib + fi, P.M - 1);
-        // the row's block exponents: one 8-byte load (bytes past KB belong to other blocks and are never consulted)
-        const unsigned long long pk = *reinterpret_cast<const unsigned long long *>(P.xe + (int64_t)m * P.ldxe);
-        epack[ib] = pk;
-        eiu[ib] = eimax[ib] = (int)(pk & 0xffu);
-        const int mr = m0 + wm * 64 + 32 * ib + fi;
-        rv[ib] = P.rowvec ? P.rowvec[mr < P.M ? mr : P.M - 1] : 0.f;
-    }
-    float winv = *reinterpret_cast<const float *>(P.wp);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // K step 0 has landed (and the plain loads above)
-    // the compiler does not see that wait: pin every loaded value here, or it places its own full wait at the
-    // first use -- inside the loop (draining the ring at every block boundary) or in front of the epilogue
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib) {
-        unsigned lo = (unsigned)epack[ib], hi = (unsigned)(epack[ib] >> 32);
-        asm volatile("" : "+v"(lo), "+v"(hi), "+v"(rv[ib]));
-        epack[ib] = ((unsigned long long)hi << 32) | lo;
-    }
-#pragma unroll
-    for (int j = 0; j < SP_NPAR; ++j) asm volatile("" : "+v"(par[j]));
-    asm volatile("" : "+v"(winv));
-    lds_barrier();
-
-#ifdef SP_STAMP
-    const bool stamp_on = blockIdx.x == gridDim.x / 2 + 3 && tid == 0;
-    if (stamp_on) { g_sp_stamps[0] = __builtin_amdgcn_s_memtime(); g_sp_stamps[1] = __builtin_amdgcn_s_memrealtime(); }
-#endif
-#ifdef SP_PRIO
-    if (wid >= 4) __builtin_amdgcn_s_setprio(1);           // the younger half loses VALU/issue arbitration otherwise
-#endif
-    for (int ks = 0; ks < KS; ++ks) {
-        const char *cur = smem + (ks & 1) * SP_STAGE;
-#ifndef SP_KNOCK_DMA
-        if (ks + 1 < KS) dma(ks + 1);                  // the other stage: last read during step ks - 1
-#endif
-        if ((ks & 7) == 0 && ks > 0) {
-            // block boundary: re-express the accumulators in the next block's unit
-            const int kb = ks >> 3;
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib) {
-                const int ei = (int)((epack[ib] >> (8 * kb)) & 0xffu);
-                eimax[ib] = max(eimax[ib], ei);
-                const int enew = max(ei, eimax[ib] - 40);
-                const int d = max(eiu[ib] - enew, -126);
-                eiu[ib] = enew;
-                const float ratio = __uint_as_float((unsigned)(127 + d) << 23);
-#pragma unroll
-                for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[ib][jb][r] *= ratio;
-            }
-        }
-        f16x8 fw[2][4][2], fx[2][2][2];
-        auto read_frags = [&](int s, f16x8 (&a)[4][2], f16x8 (&b)[2][2]) {
-            const int c1 = ((2 * s + fh) ^ sw) << 4, c2 = ((4 + 2 * s + fh) ^ sw) << 4;
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib) {
-                b[ib][0] = *reinterpret_cast<const f16x8 *>(cur + xrow + c1 + 32 * ib * SP_ROWB);
-                b[ib][1] = *reinterpret_cast<const f16x8 *>(cur + xrow + c2 + 32 * ib * SP_ROWB);
-            }
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb) {
-                a[jb][0] = *reinterpret_cast<const f16x8 *>(cur + wrow + c1 + 32 * jb * SP_ROWB);
-                a[jb][1] = *reinterpret_cast<const f16x8 *>(cur + wrow + c2 + 32 * jb * SP_ROWB);
-            }
-        };
-        read_frags(0, fw[0], fx[0]);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            if (s + 1 < 2) read_frags(s + 1, fw[(s + 1) & 1], fx[(s + 1) & 1]);
-            f16x8 (&a)[4][2] = fw[s & 1];
-            f16x8 (&b)[2][2] = fx[s & 1];
-            // term-major order, the small terms first: eight MFMAs between two writes of the same accumulator
-#define SP_TERM(QW, QX)                                                                                   \
-    _Pragma("unroll") for (int ib = 0; ib < 2; ++ib) _Pragma("unroll") for (int jb = 0; jb < 4; ++jb)      \
-        acc[ib][jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[jb][QW], b[ib][QX], acc[ib][jb], 0, 0, 0);
-#ifndef SP_KNOCK_MFMA
-            SP_TERM(1, 0)
-            SP_TERM(0, 1)
-            SP_TERM(0, 0)
-#else
-            acc[0][0][0] += (float)a[0][0][0] + (float)b[0][0][0];
-#endif
-#undef SP_TERM
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of step ks + 1 have landed
-        lds_barrier();                                      // stage ks & 1 fully read, stage (ks + 1) & 1 complete
-    }
-
-#ifdef SP_STAMP
-    if (stamp_on) { g_sp_stamps[2] = __builtin_amdgcn_s_memtime(); g_sp_stamps[3] = __builtin_amdgcn_s_memrealtime(); }
-#endif
-#ifdef SP_PRIO
-    if (wid >= 4) __builtin_amdgcn_s_setprio(0);
-#endif
-    // park the epilogue parameters behind the staging tiles
-    if (tid < SP_BN) {
-#pragma unroll
-        for (int j = 0; j < SP_NPAR; ++j) cpar[j * SP_BN + tid] = par[j];
-        rowmax[tid] = 0u;
-    }
-    lds_barrier();
-
-    // ================================================ epilogue ================================================
-    // lane (fi, fh) of block (ib, jb) holds row 32 ib + fi, columns 32 jb + 8 g + 4 fh + (0..3), g = register quad
-    const int act = P.epi.act;
-    const bool relu = act == BLGNN_ACT_RELU;                   // GEN = false: relu or identity
-    const int mrow0 = m0 + wm * 64 + fi;
-    float rsc[2];
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib) rsc[ib] = __uint_as_float((unsigned)eiu[ib] << 23) * winv;
-    // straight-line: the staged parameters hold neutral values where the caller passed none (scale 1, shift 0,
-    // rank-1 factor 0), so no branch splits the accumulators' live ranges; row blocks innermost, so a column
-    // group's parameters are read once
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int nl = wn * 128 + 32 * jb + 8 * g + 4 * fh;
-            const float4 b4 = *reinterpret_cast<const float4 *>(cpar + nl);
-            const float4 w4 = *reinterpret_cast<const float4 *>(cpar + SP_BN + nl);
-            const float4 s4 = *reinterpret_cast<const float4 *>(cpar + 2 * SP_BN + nl);
-            const float4 t4 = *reinterpret_cast<const float4 *>(cpar + 3 * SP_BN + nl);
-            const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
-            const float sc[4] = {s4.x, s4.y, s4.z, s4.w}, sh[4] = {t4.x, t4.y, t4.z, t4.w};
-            float sl[4] = {0.f, 0.f, 0.f, 0.f};
-            if (GEN) {
-                const float4 p4 = *reinterpret_cast<const float4 *>(cpar + 4 * SP_BN + nl);
-                sl[0] = p4.x; sl[1] = p4.y; sl[2] = p4.z; sl[3] = p4.w;
-            }
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v = acc[ib][jb][4 * g + q] * rsc[ib];
-                    v = fmaf(rv[ib], ww[q], v + bb[q]);
-                    if (GEN) v = apply_act(v, act, sl[q]);
-                    else v = (relu && !(v > 0.f)) ? 0.f : v;
-                    acc[ib][jb][4 * g + q] = fmaf(v, sc[q], sh[q]);
-                }
-        }
-    // every wave passed the barrier that ended the last K step: the operand stages are free.  Wave-private
-    // staging tile (LDS operations of one wave complete in order: no barrier between its writes and reads).
-    char *stg = smem + wid * SP_OWAVE;
-    if (P.y) {
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib) {
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 v = make_float4(acc[ib][jb][4 * g], acc[ib][jb][4 * g + 1], acc[ib][jb][4 * g + 2],
-                                                 acc[ib][jb][4 * g + 3]);
-                    *reinterpret_cast<float4 *>(stg + fi * SP_OSTRIDE + (32 * jb + 8 * g + 4 * fh) * 4) = v;
-                }
-            const int mb = m0 + wm * 64 + 32 * ib;
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int t = lane + 64 * it, row = t >> 5, c4 = t & 31;
-                const float4 v = *reinterpret_cast<const float4 *>(stg + row * SP_OSTRIDE + c4 * 16);
-                if (mb + row < P.M)
-                    *reinterpret_cast<float4 *>(P.y + (int64_t)(mb + row) * P.ldy + n0 + wn * 128 + c4 * 4) = v;
-            }
-        }
-    }
-    if (P.ys) {
-        // block scale = the row's largest magnitude over the tile's 256 columns (this wave + its column neighbour)
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib) {
-            float mx = 0.f;
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[ib][jb][r]));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
-            if (fh == 0) atomicMax(rowmax + wm * 64 + 32 * ib + fi, __float_as_uint(mx));
-        }
-        lds_barrier();
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib) {
-            float s, inv;
-            pow2_scale(__uint_as_float(rowmax[wm * 64 + 32 * ib + fi]), s, inv);
-            const int m = mrow0 + 32 * ib;
-            if (wn == 0 && fh == 0 && m < P.M) P.ye[(int64_t)m * P.ldye + (n0 >> 8)] = sp_exp_of(inv);
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4v v = {acc[ib][jb][4 * g] * s, acc[ib][jb][4 * g + 1] * s, acc[ib][jb][4 * g + 2] * s,
-                                      acc[ib][jb][4 * g + 3] * s};
-                    const f16x4 h1 = __builtin_convertvector(v, f16x4);
-                    const f16x4 h2 = __builtin_convertvector(v - __builtin_convertvector(h1, f32x4v), f16x4);
-                    char *dst = stg + fi * SP_OSTRIDE + jb * 128 + (8 * g + 4 * fh) * 2;
-                    *reinterpret_cast<f16x4 *>(dst) = h1;
-                    *reinterpret_cast<f16x4 *>(dst + 64) = h2;
-                }
-            const int mb = m0 + wm * 64 + 32 * ib;
-            char *yrow = reinterpret_cast<char *>(P.ys) + ((n0 + wn * 128) >> 5) * 128;
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int t = lane + 64 * it, row = t >> 5, pc = t & 31;
-                const float4 v = *reinterpret_cast<const float4 *>(stg + row * SP_OSTRIDE + pc * 16);
-                if (mb + row < P.M)
-                    *reinterpret_cast<float4 *>(yrow + (int64_t)(mb + row) * P.ldys * 2 + pc * 16) = v;
-            }
-        }
-    }
-#ifdef SP_STAMP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (stamp_on) { g_sp_stamps[4] = __builtin_amdgcn_s_memtime(); g_sp_stamps[5] = __builtin_amdgcn_s_memrealtime(); }
-#endif
-}
-
-// The same GEMM on v_mfma_f32_16x16x32_f16: one MFMA per K step of 32 and 16 x 16 block (96 per wave and step, 16 cycles
-// each: the cycles of the 32 x 32 x 16 form).  Why: the loop is power-limited (in-kernel clock 1.5 GHz with both operand
-// streams running, 1.9 GHz without them, 2.4 GHz without the MFMAs), and the 16 x 16 shape holds a higher clock at equal
-// cycles per flop.  A lane owns FOUR rows (one per 16-row block) and, per accumulator, four consecutive columns.
-// (Tried and dropped: a persistent form -- one workgroup per CU walking its tiles, the next tile's first operand stage
-// and row parameters requested before the current tile's epilogue, 16-row staging passes out of the stage-1 region --
-// to hide the ~14 us of a tile's 90 that are neither main loop nor epilogue: 2 746 vs 2 591 us at K = N = 1024, 1 046 vs
-// 1 002 at K = 256: static tile assignment loses more than the hidden round trips gain.)
-template <bool GEN>
-__global__ void __launch_bounds__(512, 2) k_linear_sp16(const LinearSpArgs P) {
-    extern __shared__ float4 sp_smem[];
-    char *smem = reinterpret_cast<char *>(sp_smem);
-    float *cpar = reinterpret_cast<float *>(smem + SP_OSTG);                  // [SP_NPAR][256]   (epilogue only)
-    unsigned *rowmax = reinterpret_cast<unsigned *>(cpar + SP_NPAR * SP_BN);   // [256] bits of max |y| per row
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform by construction: keep it scalar
-    const int nb = P.N / SP_BN;
-    int tile;
-    {   // blocks b, b + 8, ... share an XCD: give each XCD a contiguous run of tiles (row-panel major), so the
-        // column blocks of one row panel read it from the same L2
-        const int nblk = gridDim.x, b = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = b & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    }
-    const int m0 = (tile / nb) * SP_BM, cb = tile % nb, n0 = cb * SP_BN;
-    const int KS = P.K / SP_BK;
-
-#ifdef SP_STAGGER
-    // Tiles take the same time on every CU, so all 256 workgroups of a round reach their epilogue together and the
-    // round's 64 MB of results leave in one burst at the HBM write rate (measured: 28 k of a tile's 142 k cycles)
-    // while HBM idles during the main loops.  Spread the FIRST round's starts over one tile time (32 phases of the
-    // workgroup's index inside its XCD); later rounds inherit the offsets.
-    if (blockIdx.x < 256 && gridDim.x >= 512) {
-        const int phase = (blockIdx.x >> 3) & 31;
-        const int naps = phase * (KS * 112 + 400) / 512;          // x 64 x 8 cycles each: phase / 32 of ~ (3.6 k KS + 13 k) cycles
-        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(8);
-    }
-#endif
 
     // ---- LDS-DMA plan: per K step this wave brings 32 X rows and 32 W columns (4 + 4 pieces of 1 KB) ----------
     // piece i of X: rows 32 wid + 8 i + (lane >> 3), LDS slot lane & 7 <- global chunk slot ^ ((row >> 1) & 7).
@@ -509,15 +198,11 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp16(const LinearSpArgs P) {
     auto dma_piece = [&](int ks, int p) {                   // piece p of K step ks: 0..3 X rows, 4..7 W columns
         char *st = smem + (ks & 1) * SP_STAGE;
         if (p < 4) {
-#ifndef SP_KNOCK_XDMA
             __builtin_amdgcn_raw_ptr_buffer_load_lds(RX, (sp_lds_void *)(st + (32 * wid + 8 * p) * SP_ROWB), 16,
-                                                     (p & 1) ? xv1 : xv0, xs0 + 8 * p * (int)rowb + ks * SP_ROWB, 0, SP_X_AUX);
-#endif
+                                                     (p & 1) ? xv1 : xv0, xs0 + 8 * p * (int)rowb + ks * SP_ROWB, 0, 0);
         } else {
-#ifndef SP_KNOCK_WDMA
             __builtin_amdgcn_raw_ptr_buffer_load_lds(RW, (sp_lds_void *)(st + SP_XST + wid * 4096 + (p - 4) * 1024), 16, wv,
                                                      ks * SP_WST + wid * 4096 + (p - 4) * 1024, 0, 0);
-#endif
         }
     };
     auto dma = [&](int ks) {
@@ -586,9 +271,6 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp16(const LinearSpArgs P) {
     const bool stamp_on = blockIdx.x == gridDim.x / 2 + 3 && tid == 0;
     if (stamp_on) { g_sp_stamps[0] = __builtin_amdgcn_s_memtime(); g_sp_stamps[1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
-#ifdef SP_PRIO
-    if (wid >= 4) __builtin_amdgcn_s_setprio(1);           // the younger half loses VALU/issue arbitration otherwise
-#endif
     for (int ks = 0; ks < KS; ++ks) {
         const char *cur = smem + (ks & 1) * SP_STAGE;
 #ifndef SP_KNOCK_DMA
@@ -646,9 +328,6 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp16(const LinearSpArgs P) {
 
 #ifdef SP_STAMP
     if (stamp_on) { g_sp_stamps[2] = __builtin_amdgcn_s_memtime(); g_sp_stamps[3] = __builtin_amdgcn_s_memrealtime(); }
-#endif
-#ifdef SP_PRIO
-    if (wid >= 4) __builtin_amdgcn_s_setprio(0);
 #endif
     // park the epilogue parameters behind the staging tiles
     if (tid < SP_BN) {
@@ -778,19 +457,6 @@ static int launch_linear_sp_t(const LinearSpArgs &P, hipStream_t s) {
         declared = true;
     }
     const int64_t blocks = (int64_t)((P.M + SP_BM - 1) / SP_BM) * (P.N / SP_BN);
-    // default: the 16 x 16 x 32 form (3-4 % faster: higher sustained clock); BLGNN_SP_MFMA16=0 pins the 32 x 32 x 16 kernel
-    static const bool m16 = [] { const char *e = getenv("BLGNN_SP_MFMA16"); return !(e && e[0] == '0'); }();
-    if (m16) {
-        static bool declared16 = false;
-        if (!declared16) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_sp16<GEN>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS) != hipSuccess)
-                return fail(BLGNN_ERR_LAUNCH, "linear_sp: cannot raise the dynamic LDS limit to %d bytes", SP_LDS);
-            declared16 = true;
-        }
-        hipLaunchKernelGGL(k_linear_sp16<GEN>, dim3((unsigned)blocks), dim3(512), SP_LDS, s, P);
-        return launch_status("linear_sp");
-    }
     hipLaunchKernelGGL(k_linear_sp<GEN>, dim3((unsigned)blocks), dim3(512), SP_LDS, s, P);
     return launch_status("linear_sp");
 }
