@@ -109,7 +109,7 @@ class GMNPropagator(nn.Module):
         if self.training and torch.is_grad_enabled():
             return self._forward_train(x, csr, merge, model)
         if self._use_sp(n, D):
-            return self._forward_sp(x, csr, merge, model)
+            return self._forward_sp(x, csr, merge, model, batch_data)
         with torch.no_grad():
             wpq, bpq, _, _ = self._message_weights()
             w1, b1, rw = self._node_weights()
@@ -141,13 +141,13 @@ class GMNPropagator(nn.Module):
                 cur = torch.cuda.current_stream(x.device)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    ops.gmn_match(seg, x, out=f_in[:, 3 * D:], row_amax=af)
+                    ops.gmn_match(seg, x, out=f_in[:, 3 * D:], row_amax=af, max_nodes=self._max_nodes(batch_data))
             pq = ops.linear(x, wpq, bpq, row_amax=ax)                     # [n, 4D] = [P | Q]
             ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:], out=f_in[:, D:3 * D], row_amax=af)
             if side is not None:
                 cur.wait_stream(side)
             else:
-                ops.gmn_match(seg, x, out=f_in[:, 3 * D:], row_amax=af)
+                ops.gmn_match(seg, x, out=f_in[:, 3 * D:], row_amax=af, max_nodes=self._max_nodes(batch_data))
             if af is None and hid_amax is not None:
                 af = ops.row_absmax(f_in)
             hid = ops.linear(f_in, w1, b1, act=act, rowvec=ops.row_degree(csr), rowvec_w=rw, amax_out=hid_amax, row_amax=af)
@@ -156,15 +156,29 @@ class GMNPropagator(nn.Module):
         return out
 
     @staticmethod
+    def _max_nodes(batch_data):
+        """largest graph of the batch, from the host-side ind_list (src/merged_graph.py:56-57), cached on the merge
+        object: the attention's size-class kernels that no pair needs are then not launched"""
+        merge = batch_data.merge_data['merge']
+        mx = getattr(merge, "_max_graph_nodes", None)
+        if mx is None:
+            ind = batch_data.merge_data.get('ind_list') if hasattr(batch_data.merge_data, "get") else None
+            mx = max((int(e) - int(s) for s, e in ind), default=0) if ind else 0
+            merge._max_graph_nodes = mx
+        return mx
+
+    @staticmethod
     def _use_sp(n, D):
         """The pre-split ("sp") pipeline: FLAGS.gmn_sp = True (default: when the GEMMs are large enough for the
         256 x 256 tiles), "force" (any size: tests) or False (the in-kernel split of blgnn_linear_h3)."""
         mode = getattr(FLAGS, "gmn_sp", True)
+        if not hasattr(ops, "SpRows"):                 # (a stand-in backend without the sp kernels: host-logic tests)
+            return False
         if not mode or getattr(FLAGS, "feature_transform", "f16x3") != "f16x3" or D % ops.SpRows.BLOCK != 0 or 4 * D > 2048:
             return False
         return mode == "force" or ops.linear_sp_supported(n, D, 4 * D)
 
-    def _forward_sp(self, x, csr, merge, model):
+    def _forward_sp(self, x, csr, merge, model, batch_data):
         """Eval forward with every GEMM operand in the sp format (include/blgnn.h: blgnn_linear_sp): each producer
         splits its result ONCE into two fp16 piece planes with a power-of-two scale per (row, 256 columns) -- the
         GIN layer x (its store loop), the edge kernel S, f_node's first Linear the hidden layer (GEMM epilogue); the
@@ -182,8 +196,10 @@ class GMNPropagator(nn.Module):
             side = self._side_stream(x.device) if (x.is_cuda and getattr(FLAGS, "gmn_overlap_match", True)) else None
             seg = merge.segments()                               # (built on the launch stream, before the fork)
 
+            max_nodes = self._max_nodes(batch_data)
+
             def match():
-                u = ops.gmn_match(seg, x)
+                u = ops.gmn_match(seg, x, max_nodes=max_nodes)
                 ops.split_rows_sp(u, out=f_sp.cols(3 * D, 4 * D))
                 return u
 

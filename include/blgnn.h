@@ -396,10 +396,13 @@ int blgnn_linear_sp(const void *xs, int64_t ldxs, const uint8_t *xe, int64_t ldx
  * u[i] = x[i] - sum_j softmax_j(cos(x_i, x_j)) x_j, j over the partner graph.
  * seg has 2*num_pairs+1 entries.
  * row_amax (optional, [rows], initialised by the caller): merged with max_c |u[i, c]| by atomic maximum
- * (see blgnn_edge_relu_sum). */
+ * (see blgnn_edge_relu_sum).
+ * max_nodes: the largest graph of the batch when the caller knows it (the reference's ind_list is a host list),
+ * 0 = unknown.  Pairs are handled by three kernels by size class (<= 64, <= 128, larger); with the hint the classes
+ * nobody is in are not launched. */
 int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const float *x,
                     int64_t ldx, float *u, int64_t ldu, int32_t d, float *row_amax,
-                    void *stream);
+                    int32_t max_nodes, void *stream);
 
 /* GMNPropagator(f_node='GRU'): the gate arithmetic of torch.nn.GRUCell (model/layers_gmn.py:27-30,48-50) on the two
  * gate tables gi = in W_ih^T + b_ih, gh = h W_hh^T + b_hh ([n, 3D], gate order r | z | n; two blgnn_linear calls):
