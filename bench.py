@@ -103,6 +103,8 @@ def parse():
                          "of a pass over it (measured: no gain)")
     ap.add_argument("--no-gmn-sp", action="store_true",
                     help="GMN configs: the in-kernel operand split of blgnn_linear_h3 instead of the pre-split pipeline")
+    ap.add_argument("--gmn-match-streams", type=int, default=1, choices=(1, 2),
+                    help="GMN configs: side streams of the cross-graph attention's size-class kernels")
     ap.add_argument("--gmn-streams", type=int, default=1,
                     help="GMN configs: consecutive steps (independent pair batches) alternate over this many streams")
     ap.add_argument("--no-fuse-readout", action="store_true",
@@ -577,6 +579,7 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
                              device=device, batch_size=batch, feature_transform=transform)
     flags.gmn_fused_amax = bool(getattr(args, "gmn_fused_amax", False))
     flags.gmn_sp = not getattr(args, "no_gmn_sp", False)
+    flags.gmn_match_streams = int(getattr(args, "gmn_match_streams", 1))
     blgnn.set_flags(flags)
     torch.manual_seed(seed)
     data = blgnn.TrainData(ds, device=device, num_hyper_edge_feat=3 if cfg["edge_types"] > 1 else 0)

@@ -54,9 +54,9 @@ class GMNPropagator(nn.Module):
     _streams = {}
 
     @classmethod
-    def _side_stream(cls, device):
-        """one side stream per launch stream (two forwards pipelined on two streams keep separate side streams)"""
-        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    def _side_stream(cls, device, index=0):
+        """side streams per launch stream (two forwards pipelined on two streams keep separate side streams)"""
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream, index)
         if key not in cls._streams:
             cls._streams[key] = torch.cuda.Stream(device=device)
         return cls._streams[key]
@@ -198,23 +198,34 @@ class GMNPropagator(nn.Module):
 
             max_nodes = self._max_nodes(batch_data)
 
-            def match():
-                u = ops.gmn_match(seg, x, max_nodes=max_nodes)
-                ops.split_rows_sp(u, out=f_sp.cols(3 * D, 4 * D))
-                return u
-
+            u = torch.empty((n, D), dtype=torch.float32, device=x.device)
             if side is not None:
+                # FLAGS.gmn_match_streams = 2 puts the two rarer size classes of the attention on a second side stream (the
+                # three kernels are independent and each leaves most of the chip idle; per layer at configs[2] they take
+                # 0.70 + 0.42 + 0.39 ms in a row).  Measured A/B in one process: 19.43 / 19.95 vs 19.32 / 19.87 ms per
+                # step with one side stream -- the chain already hides behind the message GEMM + edge kernel.  Default 1.
                 cur = torch.cuda.current_stream(x.device)
+                two = getattr(FLAGS, "gmn_match_streams", 1) >= 2
                 side.wait_stream(cur)
+                if two:
+                    side2 = self._side_stream(x.device, 1)
+                    side2.wait_stream(cur)
+                    with torch.cuda.stream(side2):
+                        ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, classes=6)
+                        u.record_stream(side2)
                 with torch.cuda.stream(side):
-                    u = match()
+                    ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, classes=1 if two else 0)
+                    if two:
+                        side.wait_stream(side2)
+                    ops.split_rows_sp(u, out=f_sp.cols(3 * D, 4 * D))
                     u.record_stream(side)
+            else:
+                ops.gmn_match(seg, x, out=u, max_nodes=max_nodes)
+                ops.split_rows_sp(u, out=f_sp.cols(3 * D, 4 * D))
             pq, _ = ops.linear_sp(f_sp.cols(0, D), wpq, bpq)                              # [n, 4D] = [P | Q], fp32
             ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:], out_sp=f_sp.cols(D, 3 * D))
             if side is not None:
                 cur.wait_stream(side)
-            else:
-                match()
             hid = ops.SpRows(n, 4 * D, x.device)
             ops.linear_sp(f_sp, w1, b1, act=act_name(self.f_node.activation), rowvec=ops.row_degree(csr), rowvec_w=rw,
                           out_sp=hid)

@@ -657,9 +657,11 @@ def segment_reduce_multi(seg, xs, kind="mean", row_map=None, out=None):
     return out
 
 
-def gmn_match(seg, x, out=None, row_amax=None, max_nodes=0):
+def gmn_match(seg, x, out=None, row_amax=None, max_nodes=0, classes=0):
     """``row_amax`` [rows]: merged with the row magnitudes of the result (atomic maximum).  ``max_nodes``: the largest
-    graph of the batch if the caller knows it (host-side ind_list), so that unused size classes are not launched."""
+    graph of the batch if the caller knows it (host-side ind_list), so that unused size classes are not launched.
+    ``classes``: bit mask of the pair size classes to process (1: both graphs <= 64 nodes, 2: 65..128, 4: larger; 0 = all)
+    -- independent kernels that a caller may put on different streams."""
     xp, ldx = _mat(x, "x")
     G = seg.numel() - 1
     if G % 2:
@@ -667,7 +669,7 @@ def gmn_match(seg, x, out=None, row_amax=None, max_nodes=0):
     u = _out(out, x.shape[0], x.shape[1], x)
     up, ldu = _mat(u, "out")
     call("blgnn_gmn_match", _vec(seg, "seg", torch.int32, False), G // 2, xp, ldx, up, ldu,
-         x.shape[1], _vec(row_amax, "row_amax"), int(max_nodes), _stream())
+         x.shape[1], _vec(row_amax, "row_amax"), int(max_nodes), int(classes), _stream())
     return u
 
 

@@ -539,7 +539,8 @@ k_gmn_match_mfma_big(const int32_t *__restrict__ seg, int32_t num_pairs, const f
 using namespace blgnn;
 
 extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const float *x, int64_t ldx,
-                               float *u, int64_t ldu, int32_t d, float *row_amax, int32_t max_nodes, void *stream) {
+                               float *u, int64_t ldu, int32_t d, float *row_amax, int32_t max_nodes, int32_t classes,
+                               void *stream) {
     BLGNN_CHECK_ARG(num_pairs >= 0 && d >= 0, "gmn_match: negative size");
     if (num_pairs == 0 || d == 0) return BLGNN_OK;
     BLGNN_CHECK_ARG(seg && x && u, "gmn_match: null pointer");
@@ -554,6 +555,11 @@ extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const floa
     // an order of magnitude slower), between 64 KiB (two 256-thread workgroups per CU) and
     // 150 KiB (one 512-thread workgroup per CU).
     hipStream_t s = (hipStream_t)stream;
+    // size classes: bit 0 = both graphs <= 64 nodes, bit 1 = a graph of 65 .. 128, bit 2 = larger (and every pair when the
+    // width rules the matrix-core kernels out); 0 = all.  The classes are independent: a caller may issue them on
+    // different streams (the three kernels each leave most of the chip idle).
+    const bool do_small = classes == 0 || (classes & 1), do_big = classes == 0 || (classes & 2),
+               do_rest = classes == 0 || (classes & 4);
     int skip_small = -1;
     if (d % MCH == 0) {                                    // matrix-core kernel for pairs up to 64 x 64 nodes
         static bool declared = false;
@@ -565,9 +571,12 @@ extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const floa
             declared = true;
         }
         const int mblocks = num_pairs < 256 * 8 ? num_pairs : 256 * 8;
-        hipLaunchKernelGGL(k_gmn_match_mfma, dim3(mblocks), dim3(256), mbytes, s, seg, num_pairs, x, ldx, u, ldu, d, row_amax);
-        int rc = launch_status("gmn_match");
-        if (rc != BLGNN_OK) return rc;
+        int rc = BLGNN_OK;
+        if (do_small) {
+            hipLaunchKernelGGL(k_gmn_match_mfma, dim3(mblocks), dim3(256), mbytes, s, seg, num_pairs, x, ldx, u, ldu, d, row_amax);
+            rc = launch_status("gmn_match");
+            if (rc != BLGNN_OK) return rc;
+        }
         // pairs with a graph of 65 .. 128 nodes: one 512-thread workgroup each, S resident in LDS
         static bool declared_big = false;
         const int bbytes = (BM * BLD + 2 * BM * MLD + 6 * BM) * (int)sizeof(float);
@@ -580,7 +589,7 @@ extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const floa
         // (max_nodes > 0: the caller knows the largest graph of the batch -- the size classes nobody is in are not
         // launched: their workgroups would each inspect their pairs' sizes and exit, 0.4 ms per call for the
         // 2 048 x 133 KB workgroups of the scalar kernel at 8 192 pairs)
-        if (max_nodes <= 0 || max_nodes > MM) {
+        if (do_big && (max_nodes <= 0 || max_nodes > MM)) {
             hipLaunchKernelGGL(k_gmn_match_mfma_big, dim3((num_pairs + BIG_PPW - 1) / BIG_PPW), dim3(512), bbytes, s, seg, num_pairs,
                                x, ldx, u, ldu, d, row_amax);
             rc = launch_status("gmn_match");
@@ -589,6 +598,7 @@ extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const floa
         skip_small = BM;
         if (max_nodes > 0 && max_nodes <= BM) return BLGNN_OK;
     }
+    if (!do_rest) return BLGNN_OK;
     size_t want = (size_t)128 * (d + 4) * sizeof(float);
     if (want < 64 * 1024) want = 64 * 1024;
     if (want > 150 * 1024) want = 150 * 1024;

@@ -399,10 +399,11 @@ int blgnn_linear_sp(const void *xs, int64_t ldxs, const uint8_t *xe, int64_t ldx
  * (see blgnn_edge_relu_sum).
  * max_nodes: the largest graph of the batch when the caller knows it (the reference's ind_list is a host list),
  * 0 = unknown.  Pairs are handled by three kernels by size class (<= 64, <= 128, larger); with the hint the classes
- * nobody is in are not launched. */
+ * nobody is in are not launched.  classes: bit mask of the size classes to run (1: both graphs <= 64 nodes, 2: a graph
+ * of 65..128, 4: larger), 0 = all -- they are independent, so a caller may issue them on different streams. */
 int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const float *x,
                     int64_t ldx, float *u, int64_t ldu, int32_t d, float *row_amax,
-                    int32_t max_nodes, void *stream);
+                    int32_t max_nodes, int32_t classes, void *stream);
 
 /* GMNPropagator(f_node='GRU'): the gate arithmetic of torch.nn.GRUCell (model/layers_gmn.py:27-30,48-50) on the two
  * gate tables gi = in W_ih^T + b_ih, gh = h W_hh^T + b_hh ([n, 3D], gate order r | z | n; two blgnn_linear calls):

@@ -611,6 +611,28 @@ def test_gmn_match(device, d, sizes):
     assert torch.equal(ops.gmn_match(seg, x.to(device)), got)      # and the result does not depend on asking for them
 
 
+def test_gmn_match_size_classes_and_hint(device):
+    """the three size-class kernels are independent: issued one class at a time into one buffer, or with the
+    largest-graph hint, the result is bit for bit that of the single call"""
+    sizes = [12, 30, 64, 64, 65, 20, 128, 3, 129, 40, 7, 200, 33, 33]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    d = 256
+    x = torch.randn(int(off[-1]), d, generator=torch.Generator().manual_seed(9)).to(device)
+    seg = torch.as_tensor(off, dtype=torch.int32, device=device)
+    ref = ops.gmn_match(seg, x)
+    out = torch.full_like(ref, float("nan"))
+    for cls in (4, 1, 2):
+        ops.gmn_match(seg, x, out=out, classes=cls)
+    assert torch.equal(out, ref)
+    assert torch.equal(ops.gmn_match(seg, x, max_nodes=max(sizes)), ref)
+    # a batch whose largest graph has 64 nodes needs only the first kernel
+    small = [12, 30, 64, 64, 20, 5]
+    off2 = np.concatenate([[0], np.cumsum(small)])
+    seg2 = torch.as_tensor(off2, dtype=torch.int32, device=device)
+    x2 = x[:int(off2[-1])].contiguous()
+    assert torch.equal(ops.gmn_match(seg2, x2, max_nodes=64), ops.gmn_match(seg2, x2))
+
+
 def test_gmn_match_on_operands_beyond_4_gib(device):
     """the output of the match is a column slice of the [Nn, 4D] f_node input; at configs[4] (657 k atoms, D = 512)
     that buffer is 5.4 GB, so byte offsets from its base do not fit 32 bits -- pairs at both ends and in the middle
