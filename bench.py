@@ -101,6 +101,9 @@ def parse():
     ap.add_argument("--gmn-fused-amax", action="store_true",
                     help="GMN configs: the producers of the f_node input merge its row magnitudes (atomic maximum) instead "
                          "of a pass over it (measured: no gain)")
+    ap.add_argument("--no-prune-last", action="store_true",
+                    help="sharded bi-level configs: compute every row of the last interaction layer, not only the rows the "
+                         "rank's pairs read")
     ap.add_argument("--no-gmn-sp", action="store_true",
                     help="GMN configs: the in-kernel operand split of blgnn_linear_h3 instead of the pre-split pipeline")
     ap.add_argument("--gmn-match-streams", type=int, default=1, choices=(1, 2),
@@ -427,7 +430,8 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
                            use_graph=not args.no_graph, overlap=not args.no_overlap,
                            fuse_lower=(False if args.no_fuse_lower else (True if args.fuse_lower else None)),
                            readout_with_upper=args.readout_with_upper,
-                           lower_cus_per_xcd=lower_cus, exchange_transformed=(True if emu else None))
+                           lower_cus_per_xcd=lower_cus, exchange_transformed=(True if emu else None),
+                           prune_last=(True if (emu and not args.no_prune_last) else (False if args.no_prune_last else None)))
     try:
         engine.capture()
         # a fresh random batch of pair ids every step (src/sampler.py:120-131), drawn ahead of the timed

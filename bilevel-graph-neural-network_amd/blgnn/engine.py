@@ -134,10 +134,13 @@ class BiLevelEngine(object):
 
     def __init__(self, model, lower_batch, upper_batches, graph, sharded=None, world_size=1,
                  use_graph=True, overlap=True, fuse_lower=None, readout_with_upper=None, lower_cus_per_xcd=None,
-                 exchange_transformed=None):
+                 exchange_transformed=None, prune_last=None):
         from .config import FLAGS
         k = FLAGS.last_lower_lyr_num
         self.model = model
+        # the last interaction-level GAT layer restricted to the rows the scored pairs read: default when sharded
+        # (a rank scores B / N pairs out of all the interaction rows), opt-in on one GPU
+        self.prune_last = bool(world_size > 1 if prune_last is None else prune_last)
         self.lower_layers = list(model.layers[:k + 1])
         self.upper_layers = list(model.layers[k + 1:-1])      # LoadInteraction ... LinkPred (no Loss)
         if isinstance(upper_batches, BatchData):
@@ -356,9 +359,29 @@ class BiLevelEngine(object):
                 sc = hf[:, d:d + 2].t().contiguous()
                 m.acts.append(first.gat_forward_from_transform(hf[:, :d], sc, b, m))
                 layers = layers[2:]
+            prune = self._prune_layer() if self.prune_last else None
             for layer in layers:
-                m.acts.append(layer(m.acts[-1], b, m))
+                if layer is prune:
+                    # the last interaction-level layer feeds only the pair scorer: compute the rows it reads
+                    layer._out_rows = self.ids_dev[parity].view(-1)
+                try:
+                    m.acts.append(layer(m.acts[-1], b, m))
+                finally:
+                    if layer is prune:
+                        layer._out_rows = None
             return m.acts[-1]
+
+    def _prune_layer(self):
+        """The last interaction-level conv layer when it is a plain GAT layer directly in front of the pair scorer and
+        the batch reads fewer than half of the interaction rows (else None: computing every row once is cheaper)."""
+        last = self.upper_layers[-2] if len(self.upper_layers) >= 2 else None
+        if not (isinstance(last, NodeEmbedding) and last.type == 'gat' and last.higher_level and not last.normalize):
+            return None
+        if self.exchange_transformed and last is self.upper_layers[1]:
+            return None
+        if 4 * self.B >= self.init_x[0].shape[0]:
+            return None
+        return last
 
     def eager_step(self, which):
         self._feed(which, 0)

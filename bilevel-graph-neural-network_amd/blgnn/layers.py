@@ -244,10 +244,12 @@ class NodeEmbedding(nn.Module):
                     x = ops.linear(h, w2, lin2.bias, act=act, act_param=slopes,
                                    bn_scale=scale, bn_shift=shift, out=out)
             elif self.type == 'gat':
+                # ``_out_rows`` (set by BiLevelEngine around the LAST interaction-level layer): only the rows the pair
+                # scorer reads are computed
                 x = ops.gat_conv(csr, ins, self.conv.weight, self.conv.att, self.conv.bias,
                                  group=getattr(FLAGS, "gat_softmax_group", "src"),
                                  slope=self.conv.negative_slope, act=act, act_param=slopes,
-                                 bn_scale=scale, bn_shift=shift, out=out)
+                                 bn_scale=scale, bn_shift=shift, out=out, rows=getattr(self, "_out_rows", None))
             else:
                 # layers.py:48-50 reads edge_attr of the LOWER merge even for upper layers;
                 # it is None in every shipped config, and only GCN would consume it.

@@ -555,9 +555,10 @@ def gat_transform(x, weight, att, h=None):
 
 
 def gat_from_transform(csr, h, sc, bias, group="src", slope=0.2, act="identity", act_param=None,
-                       bn_scale=None, bn_shift=None, out=None, accumulate=False):
+                       bn_scale=None, bn_shift=None, out=None, accumulate=False, rows=None):
     """The graph half of GATConv on an already transformed table: per-group softmax statistics and the
-    weighted neighbour sum + bias + the caller's act / eval-BN epilogue."""
+    weighted neighbour sum + bias + the caller's act / eval-BN epilogue.  ``rows`` (int64, device): only these target
+    rows are computed (the others keep whatever ``out`` held) -- the last interaction layer of a sharded forward."""
     if group not in GAT_GROUP:
         raise ValueError("softmax_group must be 'src' or 'dst'")
     n, d = h.shape
@@ -574,17 +575,17 @@ def gat_from_transform(csr, h, sc, bias, group="src", slope=0.2, act="identity",
     call("blgnn_gat_aggregate", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, hp, ldh, s_dst, s_src,
          mx, den, GAT_GROUP[group], float(slope), yp, ldy, n, d, _vec(bias, "bias"), _act(act),
          _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"),
-         int(bool(accumulate)), s)
+         int(bool(accumulate)), _vec(rows, "rows", torch.int64), 0 if rows is None else rows.numel(), s)
     return y
 
 
 def gat_conv(csr, x, weight, att, bias, group="src", slope=0.2, act="identity", act_param=None,
-             bn_scale=None, bn_shift=None, out=None, accumulate=False):
+             bn_scale=None, bn_shift=None, out=None, accumulate=False, rows=None):
     """GATConv(heads=1) + the caller's act / eval-BN epilogue."""
     if group not in GAT_GROUP:
         raise ValueError("softmax_group must be 'src' or 'dst'")
     h, sc = gat_transform(x, weight, att)
-    return gat_from_transform(csr, h, sc, bias, group, slope, act, act_param, bn_scale, bn_shift, out, accumulate)
+    return gat_from_transform(csr, h, sc, bias, group, slope, act, act_param, bn_scale, bn_shift, out, accumulate, rows)
 
 
 def gcn_conv(csr, x, weight, bias, edge_weight=None, act="identity", act_param=None,

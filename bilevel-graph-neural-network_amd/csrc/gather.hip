@@ -49,6 +49,9 @@ struct GatherArgs {
     // epilogue
     Epilogue epi;
     int32_t accumulate;
+    // optional row subset (k_gather_wide only): compute rows row_list[0 .. n_list) instead of 0 .. n
+    const int64_t *row_list;
+    int32_t n_list;
 };
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : slope * v; }
@@ -506,7 +509,9 @@ __global__ void __launch_bounds__(256) k_gather_wide(const GatherArgs A) {
     const float4 *__restrict__ X = reinterpret_cast<const float4 *>(A.x);
     const int64_t ldx4 = A.ldx >> 2, ldy4 = A.ldy >> 2, ldp4 = A.ldp >> 2;
 
-    for (int row = blockIdx.x; row < A.n; row += gridDim.x) {
+    const int nrows = A.row_list ? A.n_list : A.n;
+    for (int it = blockIdx.x; it < nrows; it += gridDim.x) {
+        const int row = A.row_list ? (int)A.row_list[it] : it;         // (a row listed twice is computed twice: same values)
         EdgeCtx<MODE> ctx;
         ctx.init(A, row);
         float4 acc[CH], prow[CH];
@@ -674,7 +679,8 @@ static void launch_vec(const GatherArgs &A, hipStream_t s) {
 
 template <int MODE, int LG, int CH>
 static void launch_wide(const GatherArgs &A, hipStream_t s) {
-    const int blocks = A.n < 256 * 32 ? A.n : 256 * 32;
+    const int rows = A.row_list ? A.n_list : A.n;
+    const int blocks = rows < 256 * 32 ? rows : 256 * 32;
     hipLaunchKernelGGL((k_gather_wide<MODE, LG, CH>), dim3(blocks), dim3(256),
                        (size_t)A.d * 16 + WIDE_EDGES * 8, s, A);
 }
@@ -698,7 +704,7 @@ template <int MODE>
 static int dispatch(const GatherArgs &A, int64_t nnz, bool extra_aligned, hipStream_t s, const char *what,
                     bool *amax_native = nullptr) {
     if (amax_native) *amax_native = false;
-    if (A.n == 0 || A.d == 0) return BLGNN_OK;
+    if (A.n == 0 || A.d == 0 || (A.row_list && A.n_list == 0)) return BLGNN_OK;
     const bool vec = (A.d % 4 == 0) && (A.ldx % 4 == 0) && (A.ldy % 4 == 0) &&
                      aligned16(A.x) && aligned16(A.y) && extra_aligned;
     const int d4 = A.d / 4;
@@ -712,6 +718,7 @@ static int dispatch(const GatherArgs &A, int64_t nnz, bool extra_aligned, hipStr
         else if (d4 <= 320) launch_wide<MODE, 64, 5>(A, s);
         else launch_wide<MODE, 64, 8>(A, s);
     } else if (MODE == MODE_SUM && vec && d4 <= 64 && nnz <= 4 * (int64_t)A.n) {   // molecular graphs
+        // (from here on a row_list is ignored: these kernels compute every row, a superset)
         if (d4 <= 16) launch_spmm_tile<16>(A, s);
         else if (d4 <= 32) launch_spmm_tile<32>(A, s);
         else launch_spmm_tile<64>(A, s);
@@ -910,8 +917,10 @@ extern "C" int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col, in
                                    const float *mx, const float *den, int32_t group, float slope,
                                    float *y, int64_t ldy, int32_t n, int32_t d, const float *bias,
                                    int32_t act, const float *act_param, const float *bn_scale,
-                                   const float *bn_shift, int32_t accumulate, void *stream) {
+                                   const float *bn_shift, int32_t accumulate, const int64_t *rows, int32_t num_rows,
+                                   void *stream) {
     if (int rc = check_csr(rowptr, col, n, nnz, "gat_aggregate")) return rc;
+    BLGNN_CHECK_ARG(!rows || num_rows >= 0, "gat_aggregate: negative row count");
     BLGNN_CHECK_ARG(group == BLGNN_GAT_GROUP_SRC || group == BLGNN_GAT_GROUP_DST,
                     "gat_aggregate: bad group");
     BLGNN_CHECK_ARG(d >= 0 && (n == 0 || d == 0 || (h && y && s_dst && s_src && mx && den)),
@@ -924,6 +933,7 @@ extern "C" int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col, in
     A.s_dst = s_dst; A.s_src = s_src; A.mx = mx; A.den = den; A.group = group; A.slope = slope;
     A.epi = Epilogue{bias, act_param, bn_scale, bn_shift, act};
     A.accumulate = accumulate;
+    A.row_list = rows; A.n_list = rows ? num_rows : 0;
     return dispatch<MODE_GAT>(A, nnz, true, (hipStream_t)stream, "gat_aggregate");
 }
 

@@ -261,14 +261,19 @@ int blgnn_gat_softmax_stats(const int32_t *rowptr, const int32_t *col, int64_t n
 /* Step 3: y[i] (+)= epi( sum_{j in N(i) u {i}} alpha_ij h_j + bias ),
  * alpha_ij = exp(a_ij - mx[g]) / (den[g] + 1e-16), g = j (SRC) or i (DST).
  * accumulate != 0 adds into y (NodeModelAggrByEdge: model/layers_meta.py:74-79);
- * the epilogue (act, then affine) is applied to the value being written. */
+ * the epilogue (act, then affine) is applied to the value being written.
+ * rows / num_rows (optional): compute only the target rows rows[0 .. num_rows) (int64 device array, duplicates
+ * allowed) and leave every other row of y untouched -- the LAST interaction-level layer feeds only the rows the pair
+ * scorer reads (model/layers_link_pred.py:56-61), so a rank of a sharded job need not compute the others.  Honoured
+ * by the high-degree (one workgroup per row) kernel; low-degree graphs compute every row. */
 int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                         const float *h, int64_t ldh, const float *s_dst,
                         const float *s_src, const float *mx, const float *den,
                         int32_t group, float slope, float *y, int64_t ldy,
                         int32_t n, int32_t d, const float *bias, int32_t act,
                         const float *act_param, const float *bn_scale,
-                        const float *bn_shift, int32_t accumulate, void *stream);
+                        const float *bn_shift, int32_t accumulate, const int64_t *rows, int32_t num_rows,
+                        void *stream);
 
 /* GMN message: model/layers_gmn.py:38-42 restructured:
  * y[i] = sum_{e: key_e = i} relu(p[i] + q[nbr_e])  (self loops kept).

@@ -107,7 +107,7 @@ def gin_layer_x6_supported(csr, x, K, N):
 
 
 def gat_conv(csr, x, weight, att, bias, group="src", slope=0.2, act="identity", act_param=None,
-             bn_scale=None, bn_shift=None, out=None, accumulate=False):
+             bn_scale=None, bn_shift=None, out=None, accumulate=False, rows=None):
     v = oracle.gat_conv(x, csr.edge_index, weight, att, bias, group, slope)
     if accumulate:
         v = v + out

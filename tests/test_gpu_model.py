@@ -329,6 +329,49 @@ def test_engine_exchange_after_first_transform_is_bitwise_the_replicated_forward
                 assert torch.equal(out, refs[i % 2]), (use_graph, i)
 
 
+def test_engine_last_interaction_layer_pruned_to_scored_rows(device):
+    """a rank of a sharded job scores few pairs out of all the interaction rows: the LAST interaction-level GAT layer
+    then computes only the rows the pair scorer reads (blgnn_gat_aggregate's row list; model/layers_link_pred.py:56-61
+    reads nothing else).  Same kernel on those rows: the scores are bit for bit the unpruned ones; and the op itself
+    leaves every other row untouched"""
+    from blgnn import ops
+    from blgnn.engine import BiLevelEngine
+    ds = blgnn.make_synthetic(400, 9000, seed=29, device=device)      # mean interaction degree ~45: the wide gather
+    flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin",
+                             higher_level_gnn_type="gat", D_lower=128, D_higher=128, device=device,
+                             fuse_readout=False)   # bitwise comparisons: no float atomics in the readout
+    model, data = build(flags, ds, seed=9)
+    lower = blgnn.BatchData(all_molecule_pairs(ds.molecules.gids), ds, is_train=False, ignore_pairs=True)
+    g = ds.interaction_combo_nxgraph
+    g.init_x = torch.zeros((ds.num_graphs(), 5 * 128), device=device)
+    ds.init = True
+    uppers = [blgnn.BatchData(_pairs(ds, 48, seed=k), ds, is_train=False) for k in range(2)]
+    plain = BiLevelEngine(model, lower, uppers, g, use_graph=False, prune_last=False)
+    assert plain._prune_layer() is not None and not plain.prune_last
+    refs = [plain.eager_step(i).clone() for i in range(2)]
+    for use_graph in (False, True):
+        with BiLevelEngine(model, lower, uppers, g, use_graph=use_graph, prune_last=True) as eng:
+            eng.capture()
+            for i in range(4):
+                out = eng.step(i)
+                eng.synchronize()
+                assert torch.equal(out, refs[i % 2]), (use_graph, i)
+    # op level: listed rows (with a duplicate) equal the full result, the others keep the sentinel
+    csr = uppers[0].merge_higher_level['merge'].csr()
+    n, d = csr.n, 128
+    gen = torch.Generator().manual_seed(3)
+    h = torch.randn(n, d, generator=gen).to(device)
+    sc = torch.randn(2, n, generator=gen).to(device)
+    bias = torch.randn(d, generator=gen).to(device)
+    full = ops.gat_from_transform(csr, h, sc, bias, act="relu")
+    rows = torch.tensor([5, 17, 5, n - 1, 0, 123], dtype=torch.int64, device=device)
+    part = torch.full_like(full, -7.0)
+    ops.gat_from_transform(csr, h, sc, bias, act="relu", out=part, rows=rows)
+    keep = torch.zeros(n, dtype=torch.bool, device=device)
+    keep[rows] = True
+    assert torch.equal(part[keep], full[keep]) and bool((part[~keep] == -7.0).all())
+
+
 def test_engine_follows_weight_updates_after_capture(device):
     """captured graphs hold pointers to tensors derived from the weights (packed images, folded BN affines):
     an in-place weight / running-stat update after capture() must not leave step() replaying stale values"""
