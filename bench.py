@@ -106,6 +106,8 @@ def parse():
                          "rank's pairs read")
     ap.add_argument("--no-gmn-sp", action="store_true",
                     help="GMN configs: the in-kernel operand split of blgnn_linear_h3 instead of the pre-split pipeline")
+    ap.add_argument("--gmn-match-fork", choices=("message", "edge"), default=None,
+                    help="GMN configs: the attention's side stream forks beside the message GEMM or beside the edge kernel")
     ap.add_argument("--gmn-match-streams", type=int, default=1, choices=(1, 2),
                     help="GMN configs: side streams of the cross-graph attention's size-class kernels")
     ap.add_argument("--gmn-streams", type=int, default=1,
@@ -584,6 +586,8 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
     flags.gmn_fused_amax = bool(getattr(args, "gmn_fused_amax", False))
     flags.gmn_sp = not getattr(args, "no_gmn_sp", False)
     flags.gmn_match_streams = int(getattr(args, "gmn_match_streams", 1))
+    if getattr(args, "gmn_match_fork", None):
+        flags.gmn_match_fork = args.gmn_match_fork
     blgnn.set_flags(flags)
     torch.manual_seed(seed)
     data = blgnn.TrainData(ds, device=device, num_hyper_edge_feat=3 if cfg["edge_types"] > 1 else 0)

@@ -199,11 +199,10 @@ class GMNPropagator(nn.Module):
             max_nodes = self._max_nodes(batch_data)
 
             u = torch.empty((n, D), dtype=torch.float32, device=x.device)
-            if side is not None:
-                # FLAGS.gmn_match_streams = 2 puts the two rarer size classes of the attention on a second side stream (the
-                # three kernels are independent and each leaves most of the chip idle; per layer at configs[2] they take
-                # 0.70 + 0.42 + 0.39 ms in a row).  Measured A/B in one process: 19.43 / 19.95 vs 19.32 / 19.87 ms per
-                # step with one side stream -- the chain already hides behind the message GEMM + edge kernel.  Default 1.
+
+            def fork_match():
+                # FLAGS.gmn_match_streams = 2 puts the two rarer size classes of the attention on a second side stream
+                # (the three kernels are independent and each leaves most of the chip idle)
                 cur = torch.cuda.current_stream(x.device)
                 two = getattr(FLAGS, "gmn_match_streams", 1) >= 2
                 side.wait_stream(cur)
@@ -219,13 +218,25 @@ class GMNPropagator(nn.Module):
                         side.wait_stream(side2)
                     ops.split_rows_sp(u, out=f_sp.cols(3 * D, 4 * D))
                     u.record_stream(side)
+
+            # Where the attention forks off (FLAGS.gmn_match_fork): "message" (default) = beside the message GEMM AND the
+            # edge kernel, "edge" = beside the edge kernel only.  The attention's workgroups (66-133 KB of LDS) and the
+            # GEMM's (141 KB) exclude each other on a CU, so beside the GEMM the two add up (the K = 256 GEMM stretches from
+            # 1.0 to 1.85 ms in the step's kernel trace); the edge kernel is HBM-bound and uses no LDS, but its 0.6 ms do
+            # not cover the attention's 1.2-1.7 ms chain.  Measured A/B in one process (ms per step, configs[2]):
+            # message 20.04 / 19.95, edge 20.82 / 20.74; with two attention streams 20.07 / 20.07 and 20.60 / 20.40.
+            fork = getattr(FLAGS, "gmn_match_fork", "message") if side is not None else None
+            if fork == "message":
+                fork_match()
+            pq, _ = ops.linear_sp(f_sp.cols(0, D), wpq, bpq)                              # [n, 4D] = [P | Q], fp32
+            if fork == "edge":
+                fork_match()
+            ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:], out_sp=f_sp.cols(D, 3 * D))
+            if side is not None:
+                torch.cuda.current_stream(x.device).wait_stream(side)
             else:
                 ops.gmn_match(seg, x, out=u, max_nodes=max_nodes)
                 ops.split_rows_sp(u, out=f_sp.cols(3 * D, 4 * D))
-            pq, _ = ops.linear_sp(f_sp.cols(0, D), wpq, bpq)                              # [n, 4D] = [P | Q], fp32
-            ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:], out_sp=f_sp.cols(D, 3 * D))
-            if side is not None:
-                cur.wait_stream(side)
             hid = ops.SpRows(n, 4 * D, x.device)
             ops.linear_sp(f_sp, w1, b1, act=act_name(self.f_node.activation), rowvec=ops.row_degree(csr), rowvec_w=rw,
                           out_sp=hid)
