@@ -848,7 +848,7 @@ def gat_forward_saved(csr, x, weight, att, bias, group="src", slope=0.2, act="id
     yp, ldy = _mat(y, "out")
     call("blgnn_gat_aggregate", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, hp, ldh, sc[0].data_ptr(),
          sc[1].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), GAT_GROUP[group], float(slope), yp, ldy, n, d,
-         _vec(bias, "bias"), _act(act), None, None, None, int(bool(accumulate)), s)
+         _vec(bias, "bias"), _act(act), None, None, None, int(bool(accumulate)), None, 0, s)
     return y, h, sc, stats
 
 

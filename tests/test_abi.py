@@ -65,3 +65,26 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".sh")):
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_every_ctypes_call_site_passes_the_declared_number_of_arguments():
+    """a call site that lags behind a signature change only fails on a GPU box (ctypes raises at call time); count the
+    arguments of every ``call("blgnn_*", ...)`` in the package statically (calls that splat a tuple are skipped)"""
+    import ast
+    import glob
+    import os
+    from blgnn import _lib
+    pkg = os.path.dirname(os.path.abspath(_lib.__file__))
+    checked = 0
+    for path in glob.glob(os.path.join(pkg, "*.py")):
+        for node in ast.walk(ast.parse(open(path).read())):
+            if not (isinstance(node, ast.Call) and getattr(node.func, "id", getattr(node.func, "attr", None)) == "call"):
+                continue
+            if not node.args or not isinstance(node.args[0], ast.Constant) or not str(node.args[0].value).startswith("blgnn_"):
+                continue
+            if any(isinstance(a, ast.Starred) for a in node.args):
+                continue
+            name = node.args[0].value
+            assert len(node.args) - 1 == len(_lib.SIGNATURES[name]), (os.path.basename(path), node.lineno, name)
+            checked += 1
+    assert checked > 40
