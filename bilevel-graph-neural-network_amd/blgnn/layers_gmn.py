@@ -168,6 +168,17 @@ class GMNPropagator(nn.Module):
         return mx
 
     @staticmethod
+    def _pair_order(batch_data, device):
+        """the batch's pairs grouped by size class (ops.match_pair_order), cached on the merge object"""
+        merge = batch_data.merge_data['merge']
+        po = getattr(merge, "_match_pair_order", None)
+        if po is None and hasattr(ops, "match_pair_order"):
+            ind = batch_data.merge_data.get('ind_list') if hasattr(batch_data.merge_data, "get") else None
+            po = ops.match_pair_order(ind, device) if ind else None
+            merge._match_pair_order = po
+        return po
+
+    @staticmethod
     def _use_sp(n, D):
         """The pre-split ("sp") pipeline: FLAGS.gmn_sp = True (default: when the GEMMs are large enough for the
         256 x 256 tiles), "force" (any size: tests) or False (the in-kernel split of blgnn_linear_h3)."""
@@ -197,6 +208,7 @@ class GMNPropagator(nn.Module):
             seg = merge.segments()                               # (built on the launch stream, before the fork)
 
             max_nodes = self._max_nodes(batch_data)
+            order = self._pair_order(batch_data, x.device)
 
             u = torch.empty((n, D), dtype=torch.float32, device=x.device)
 
@@ -210,10 +222,10 @@ class GMNPropagator(nn.Module):
                     side2 = self._side_stream(x.device, 1)
                     side2.wait_stream(cur)
                     with torch.cuda.stream(side2):
-                        ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, classes=6)
+                        ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, classes=6, order=order)
                         u.record_stream(side2)
                 with torch.cuda.stream(side):
-                    ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, classes=1 if two else 0)
+                    ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, classes=1 if two else 0, order=order)
                     if two:
                         side.wait_stream(side2)
                     ops.split_rows_sp(u, out=f_sp.cols(3 * D, 4 * D))
@@ -236,7 +248,7 @@ class GMNPropagator(nn.Module):
             if side is not None:
                 torch.cuda.current_stream(x.device).wait_stream(side)
             else:
-                ops.gmn_match(seg, x, out=u, max_nodes=max_nodes)
+                ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, order=order)
                 ops.split_rows_sp(u, out=f_sp.cols(3 * D, 4 * D))
             hid = ops.SpRows(n, 4 * D, x.device)
             ops.linear_sp(f_sp, w1, b1, act=act_name(self.f_node.activation), rowvec=ops.row_degree(csr), rowvec_w=rw,

@@ -658,11 +658,24 @@ def segment_reduce_multi(seg, xs, kind="mean", row_map=None, out=None):
     return out
 
 
-def gmn_match(seg, x, out=None, row_amax=None, max_nodes=0, classes=0):
+def match_pair_order(ind_list, device):
+    """-> (order int32 device tensor, counts int32[4] numpy): the pair indices of a batch grouped by the size of their
+    larger graph (<= 32, <= 64, <= 128, larger), from the host-side list of node ranges (src/merged_graph.py:56-57)."""
+    import numpy as np
+    sizes = np.asarray([int(e) - int(s) for s, e in ind_list], dtype=np.int64)
+    big = np.maximum(sizes[0::2], sizes[1::2][:len(sizes[0::2])]) if len(sizes) else sizes
+    cls = np.where(big <= 0, 4, np.where(big <= 32, 0, np.where(big <= 64, 1, np.where(big <= 128, 2, 3))))
+    order = np.argsort(cls, kind="stable")
+    counts = np.bincount(cls, minlength=5)[:4].astype(np.int32)
+    order = order[:int(counts.sum())].astype(np.int32)
+    return torch.as_tensor(order).to(device), np.ascontiguousarray(counts)
+
+
+def gmn_match(seg, x, out=None, row_amax=None, max_nodes=0, classes=0, order=None):
     """``row_amax`` [rows]: merged with the row magnitudes of the result (atomic maximum).  ``max_nodes``: the largest
     graph of the batch if the caller knows it (host-side ind_list), so that unused size classes are not launched.
     ``classes``: bit mask of the pair size classes to process (1: both graphs <= 64 nodes, 2: 65..128, 4: larger; 0 = all)
-    -- independent kernels that a caller may put on different streams."""
+    -- independent kernels that a caller may put on different streams.  ``order``: ``match_pair_order(...)`` of the batch."""
     xp, ldx = _mat(x, "x")
     G = seg.numel() - 1
     if G % 2:
@@ -670,7 +683,9 @@ def gmn_match(seg, x, out=None, row_amax=None, max_nodes=0, classes=0):
     u = _out(out, x.shape[0], x.shape[1], x)
     up, ldu = _mat(u, "out")
     call("blgnn_gmn_match", _vec(seg, "seg", torch.int32, False), G // 2, xp, ldx, up, ldu,
-         x.shape[1], _vec(row_amax, "row_amax"), int(max_nodes), int(classes), _stream())
+         x.shape[1], _vec(row_amax, "row_amax"), int(max_nodes), int(classes),
+         None if order is None else _vec(order[0], "order", torch.int32, False),
+         None if order is None else order[1].ctypes.data, _stream())
     return u
 
 

@@ -9,6 +9,7 @@
 // rows: lane j scores partner row j (query row read through the scalar cache),
 // then all lanes accumulate  sum_j p_j * B[j][:]  with lane-over-feature float4s.
 // Pairs too large for the LDS budget take the same code path reading global memory.
+#include <cstdlib>
 #include "common.hpp"
 
 namespace blgnn {
@@ -536,16 +537,25 @@ k_gmn_match_mfma_big(const int32_t *__restrict__ seg, int32_t num_pairs, const f
 
 }  // namespace blgnn
 
+#include "gmn_match_wave.hpp"
+
 using namespace blgnn;
 
 extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const float *x, int64_t ldx,
                                float *u, int64_t ldu, int32_t d, float *row_amax, int32_t max_nodes, int32_t classes,
-                               void *stream) {
+                               const int32_t *pair_order, const int32_t *class_counts_host, void *stream) {
     BLGNN_CHECK_ARG(num_pairs >= 0 && d >= 0, "gmn_match: negative size");
     if (num_pairs == 0 || d == 0) return BLGNN_OK;
     BLGNN_CHECK_ARG(seg && x && u, "gmn_match: null pointer");
     BLGNN_CHECK_ARG(ldx >= d && ldu >= d, "gmn_match: leading dimension < d");
     BLGNN_CHECK_ARG(x != u, "gmn_match: x and u must not alias");
+    BLGNN_CHECK_ARG((pair_order == nullptr) == (class_counts_host == nullptr), "gmn_match: pair_order and class_counts_host go together");
+    if (class_counts_host) {
+        int64_t tot = 0;
+        for (int k = 0; k < 4; ++k) { BLGNN_CHECK_ARG(class_counts_host[k] >= 0, "gmn_match: negative class count"); tot += class_counts_host[k]; }
+        BLGNN_CHECK_ARG(tot <= num_pairs, "gmn_match: class counts exceed the number of pairs");
+        if (max_nodes <= 0) max_nodes = class_counts_host[3] ? 1 << 30 : (class_counts_host[2] ? 128 : (class_counts_host[1] ? 64 : 32));
+    }
     if (d % 4 != 0 || ldx % 4 != 0 || ldu % 4 != 0 || !aligned16(x) || !aligned16(u))
         return fail(BLGNN_ERR_UNSUPPORTED,
                     "gmn_match: needs d, ldx, ldu multiples of 4 and 16-byte aligned pointers");
@@ -572,7 +582,31 @@ extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const floa
         }
         const int mblocks = num_pairs < 256 * 8 ? num_pairs : 256 * 8;
         int rc = BLGNN_OK;
-        if (do_small) {
+        // pairs up to 64 x 64: one wavefront per pair (gmn_match_wave.hpp; two launches, <= 32 and <= 64 nodes) unless
+        // the caller wants the row magnitudes merged (only the workgroup-per-pair kernel does that) or BLGNN_MATCH_WAVE=0
+        static const bool wave_ok = [] { const char *e = getenv("BLGNN_MATCH_WAVE"); return !(e && e[0] == '0'); }();
+        if (do_small && wave_ok && !row_amax && d % 32 == 0) {
+            // pair_order / class_counts_host (optional): the pair indices grouped by size class (<= 32, <= 64, <= 128,
+            // larger) -- one wavefront per listed pair, dealt to the CUs as workgroups finish
+            const int32_t *l1 = pair_order, *l2 = pair_order ? pair_order + class_counts_host[0] : nullptr;
+            const int c1 = pair_order ? class_counts_host[0] : num_pairs, c2 = pair_order ? class_counts_host[1] : num_pairs;
+            if (c1 > 0) {
+                const int b1 = (c1 + MatchWave<1>::WAVES - 1) / MatchWave<1>::WAVES;
+                hipLaunchKernelGGL(k_gmn_match_wave<1>, dim3(pair_order ? b1 : (b1 < 256 * 6 ? b1 : 256 * 6)),
+                                   dim3(MatchWave<1>::WAVES * 64), MatchWave<1>::WAVES * MatchWave<1>::FLOATS * sizeof(float), s,
+                                   seg, num_pairs, x, ldx, u, ldu, d, l1, c1);
+                rc = launch_status("gmn_match");
+                if (rc != BLGNN_OK) return rc;
+            }
+            if (c2 > 0 && (max_nodes <= 0 || max_nodes > 32)) {
+                const int b2 = (c2 + MatchWave<2>::WAVES - 1) / MatchWave<2>::WAVES;
+                hipLaunchKernelGGL(k_gmn_match_wave<2>, dim3(pair_order ? b2 : (b2 < 256 * 6 ? b2 : 256 * 6)),
+                                   dim3(MatchWave<2>::WAVES * 64), MatchWave<2>::WAVES * MatchWave<2>::FLOATS * sizeof(float), s,
+                                   seg, num_pairs, x, ldx, u, ldu, d, l2, c2);
+                rc = launch_status("gmn_match");
+                if (rc != BLGNN_OK) return rc;
+            }
+        } else if (do_small) {
             hipLaunchKernelGGL(k_gmn_match_mfma, dim3(mblocks), dim3(256), mbytes, s, seg, num_pairs, x, ldx, u, ldu, d, row_amax);
             rc = launch_status("gmn_match");
             if (rc != BLGNN_OK) return rc;

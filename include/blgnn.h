@@ -405,10 +405,15 @@ int blgnn_linear_sp(const void *xs, int64_t ldxs, const uint8_t *xe, int64_t ldx
  * max_nodes: the largest graph of the batch when the caller knows it (the reference's ind_list is a host list),
  * 0 = unknown.  Pairs are handled by three kernels by size class (<= 64, <= 128, larger); with the hint the classes
  * nobody is in are not launched.  classes: bit mask of the size classes to run (1: both graphs <= 64 nodes, 2: a graph
- * of 65..128, 4: larger), 0 = all -- they are independent, so a caller may issue them on different streams. */
+ * of 65..128, 4: larger), 0 = all -- they are independent, so a caller may issue them on different streams.
+ * pair_order (device int32, optional) / class_counts_host (host int32[4]): the pair indices grouped by the size of their
+ * larger graph (<= 32, <= 64, <= 128, larger; pairs of two empty graphs left out), as the host can derive from ind_list:
+ * the one-wavefront-per-pair kernels of the first two classes then run exactly one wavefront per listed pair instead
+ * of scanning all pairs. */
 int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const float *x,
                     int64_t ldx, float *u, int64_t ldu, int32_t d, float *row_amax,
-                    int32_t max_nodes, int32_t classes, void *stream);
+                    int32_t max_nodes, int32_t classes, const int32_t *pair_order,
+                    const int32_t *class_counts_host, void *stream);
 
 /* GMNPropagator(f_node='GRU'): the gate arithmetic of torch.nn.GRUCell (model/layers_gmn.py:27-30,48-50) on the two
  * gate tables gi = in W_ih^T + b_ih, gh = h W_hh^T + b_hh ([n, 3D], gate order r | z | n; two blgnn_linear calls):

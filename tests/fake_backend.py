@@ -139,7 +139,7 @@ def segment_reduce_multi(seg, xs, kind="mean", row_map=None, out=None):
     return _put(out, torch.cat([segment_reduce(seg, x, kind) for x in xs], dim=1))
 
 
-def gmn_match(seg, x, out=None, row_amax=None, max_nodes=0, classes=0):
+def gmn_match(seg, x, out=None, row_amax=None, max_nodes=0, classes=0, order=None):
     s = seg.tolist()
     return _put(out, oracle.gmn_match(x, [(s[i], s[i + 1]) for i in range(len(s) - 1)]))
 

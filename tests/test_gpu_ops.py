@@ -608,7 +608,9 @@ def test_gmn_match(device, d, sizes):
     assert max_err(got, ref) < TOL
     # row magnitudes merged by atomic maximum: exactly max(previous, max_c |u|), whichever kernel took the pair
     assert torch.equal(am, torch.maximum(floor, got.abs().amax(dim=1)))
-    assert torch.equal(ops.gmn_match(seg, x.to(device)), got)      # and the result does not depend on asking for them
+    # without the row magnitudes the small pairs take the wavefront-per-pair kernels (another summation order)
+    plain = ops.gmn_match(seg, x.to(device))
+    assert max_err(plain, ref) < TOL and max_err(plain, got) < 1e-5
 
 
 def test_gmn_match_size_classes_and_hint(device):
@@ -625,6 +627,11 @@ def test_gmn_match_size_classes_and_hint(device):
         ops.gmn_match(seg, x, out=out, classes=cls)
     assert torch.equal(out, ref)
     assert torch.equal(ops.gmn_match(seg, x, max_nodes=max(sizes)), ref)
+    # the same pairs handed over as per-class lists (one wavefront per listed pair instead of scanning)
+    ind = [(int(off[i]), int(off[i + 1])) for i in range(len(sizes))]
+    order = ops.match_pair_order(ind, device)
+    assert order[1].tolist() == [1, 2, 2, 2] and sorted(order[0].tolist()) == list(range(7))
+    assert torch.equal(ops.gmn_match(seg, x, order=order), ref)
     # a batch whose largest graph has 64 nodes needs only the first kernel
     small = [12, 30, 64, 64, 20, 5]
     off2 = np.concatenate([[0], np.cumsum(small)])
