@@ -14,6 +14,13 @@
 //   pass 2   U1 = G1 - diag(1 / rowsum) E G2,  U2 = G2 - diag(1 / colsum) E^T G1   per 32-column chunk, both graphs' chunk
 //            staged again: the partner's rows are the MFMA B operand, E (or E^T) rows the A operand, the own values LDS reads
 // Exact-f32 MFMA (32x32x2) throughout, summation over k in index order: the same arithmetic as k_gmn_match_mfma.
+//
+// Measured (8 192 DrugCombo-shape pairs, d = 256, pairs handed over as per-class lists): 155 us (3 569 pairs <= 32 nodes) +
+// 440 us (4 208 pairs <= 64) against 926 us for k_gmn_match_mfma on the same pairs.  What bounds it now is memory latency
+// per chunk, not the matrix cores: in-kernel stamps of one pair (25 x 16 nodes) show 8 k cycles per 32-column chunk in
+// pass 1 and 12 k in pass 2 for 1-2 k cycles of MFMA -- one chunk of prefetch (8 KB per wave, ~100 KB per CU in flight)
+// against ~3 us of loaded latency; the kernel moves 520 MB in 155 us (floor: 70 us).  Inside the propagator step the
+// gain is small (19.7 vs 19.85 ms: the attention shares the chip with the message GEMM either way).
 #pragma once
 
 namespace blgnn {
