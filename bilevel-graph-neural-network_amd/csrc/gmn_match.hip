@@ -18,7 +18,7 @@ template <int CH>
 __global__ void __launch_bounds__(512)
 k_gmn_match(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__restrict__ x,
             int64_t ldx, float *__restrict__ u, int64_t ldu, int32_t d, int32_t lds_floats, int32_t skip_small,
-            int32_t parts, float *__restrict__ amax) {
+            int32_t parts, float *__restrict__ amax, const int32_t *__restrict__ list, int32_t n_list) {
     extern __shared__ float4 smem4[];
     float *smem = reinterpret_cast<float *>(smem4);
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
@@ -136,7 +136,9 @@ k_gmn_match(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__r
             }
         }
     };
-    if (skip_small < 0) {
+    if (list) {                                            // the class's pair list: `parts` workgroups per listed pair
+        for (int item = blockIdx.x; item < n_list * parts; item += gridDim.x) process(list[item / parts], item % parts);
+    } else if (skip_small < 0) {
         for (int item = blockIdx.x; item < num_pairs * parts; item += gridDim.x) process(item / parts, item % parts);
     } else {
         // the matrix-core kernels own every pair up to skip_small nodes per graph: 64 pairs are inspected with one
@@ -396,7 +398,8 @@ k_gmn_match_mfma(const int32_t *__restrict__ seg, int32_t num_pairs, const float
 
 __global__ void __launch_bounds__(512)
 k_gmn_match_mfma_big(const int32_t *__restrict__ seg, int32_t num_pairs, const float *__restrict__ x, int64_t ldx,
-                     float *__restrict__ u, int64_t ldu, int32_t d, float *__restrict__ amax) {
+                     float *__restrict__ u, int64_t ldu, int32_t d, float *__restrict__ amax,
+                     const int32_t *__restrict__ list, int32_t n_list) {
     extern __shared__ float4 smem4[];
     float *E = reinterpret_cast<float *>(smem4);        // [BM][BLD]
     float *G1c = E + BM * BLD;                          // [BM][MLD]
@@ -411,9 +414,11 @@ k_gmn_match_mfma_big(const int32_t *__restrict__ seg, int32_t num_pairs, const f
     const unsigned xvoff = (unsigned)(lrow * ldx + 4 * lc4) * 4u;
     const unsigned uvoff = (unsigned)(4 * fh * ldu + fi) * 4u;
 
-    // which of this workgroup's BIG_PPW pairs are big: one vector load of their segment offsets
+    // which of this workgroup's BIG_PPW pairs are big: one vector load of their segment offsets -- or, with the class's
+    // pair list (one workgroup per listed pair), just that pair
     unsigned todo;
-    {
+    if (list) todo = blockIdx.x < (unsigned)n_list ? 1u : 0u;
+    else {
         const int q = lane < BIG_PPW ? lane : 0;
         const int pr = blockIdx.x + q * gridDim.x;
         bool big = false;
@@ -426,7 +431,7 @@ k_gmn_match_mfma_big(const int32_t *__restrict__ seg, int32_t num_pairs, const f
     while (todo) {
         const int q = __builtin_ctz(todo);
         todo &= todo - 1;
-        const int pair = blockIdx.x + q * gridDim.x;
+        const int pair = list ? list[blockIdx.x] : blockIdx.x + q * gridDim.x;
         const int s0 = seg[2 * pair], s1 = seg[2 * pair + 1], s2 = seg[2 * pair + 2];
         const int n1 = s1 - s0, n2 = s2 - s1;
         const int TM = (n1 + 31) >> 5, TN = (n2 + 31) >> 5;
@@ -624,15 +629,18 @@ extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const floa
         // launched: their workgroups would each inspect their pairs' sizes and exit, 0.4 ms per call for the
         // 2 048 x 133 KB workgroups of the scalar kernel at 8 192 pairs)
         if (do_big && (max_nodes <= 0 || max_nodes > MM)) {
-            hipLaunchKernelGGL(k_gmn_match_mfma_big, dim3((num_pairs + BIG_PPW - 1) / BIG_PPW), dim3(512), bbytes, s, seg, num_pairs,
-                               x, ldx, u, ldu, d, row_amax);
+            const int32_t *l3 = pair_order ? pair_order + class_counts_host[0] + class_counts_host[1] : nullptr;
+            const int c3 = pair_order ? class_counts_host[2] : 0;
+            if (!pair_order || c3 > 0)
+                hipLaunchKernelGGL(k_gmn_match_mfma_big, dim3(pair_order ? c3 : (num_pairs + BIG_PPW - 1) / BIG_PPW), dim3(512), bbytes,
+                                   s, seg, num_pairs, x, ldx, u, ldu, d, row_amax, l3, c3);
             rc = launch_status("gmn_match");
             if (rc != BLGNN_OK) return rc;
         }
         skip_small = BM;
         if (max_nodes > 0 && max_nodes <= BM) return BLGNN_OK;
     }
-    if (!do_rest) return BLGNN_OK;
+    if (!do_rest || (pair_order && skip_small >= 0 && class_counts_host[3] == 0)) return BLGNN_OK;
     size_t want = (size_t)128 * (d + 4) * sizeof(float);
     if (want < 64 * 1024) want = 64 * 1024;
     if (want > 150 * 1024) want = 150 * 1024;
@@ -640,7 +648,10 @@ extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const floa
     const int lds_floats = lds_bytes / 4;
     const int threads = lds_bytes > 80 * 1024 ? 512 : 256;
     const int parts = skip_small >= 0 ? 32 : 1;   // the rare > 128-node pairs: 32 workgroups share the query rows of each
-    const int64_t items = skip_small >= 0 ? (int64_t)(num_pairs + WAVE - 1) / WAVE * parts : (int64_t)num_pairs;
+    const int32_t *l4 = (pair_order && skip_small >= 0) ? pair_order + class_counts_host[0] + class_counts_host[1] + class_counts_host[2] : nullptr;
+    const int c4 = l4 ? class_counts_host[3] : 0;
+    const int64_t items = l4 ? (int64_t)c4 * parts
+                             : (skip_small >= 0 ? (int64_t)(num_pairs + WAVE - 1) / WAVE * parts : (int64_t)num_pairs);
     const int blocks = (int)(items < 256 * 8 ? items : 256 * 8);
     const int ch = (d / 4 + WAVE - 1) / WAVE;
 #define BLGNN_GMN_LAUNCH(CH_)                                                                       \
@@ -653,7 +664,7 @@ extern "C" int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const floa
             declared = lds_bytes;                                                                   \
         }                                                                                           \
         hipLaunchKernelGGL((k_gmn_match<CH_>), dim3(blocks), dim3(threads), lds_bytes, s, seg,      \
-                           num_pairs, x, ldx, u, ldu, d, lds_floats, skip_small, parts, row_amax); \
+                           num_pairs, x, ldx, u, ldu, d, lds_floats, skip_small, parts, row_amax, l4, c4); \
     } while (0)
     if (ch <= 1) BLGNN_GMN_LAUNCH(1);
     else if (ch == 2) BLGNN_GMN_LAUNCH(2);

@@ -616,7 +616,7 @@ def test_gmn_match(device, d, sizes):
 def test_gmn_match_size_classes_and_hint(device):
     """the three size-class kernels are independent: issued one class at a time into one buffer, or with the
     largest-graph hint, the result is bit for bit that of the single call"""
-    sizes = [12, 30, 64, 64, 65, 20, 128, 3, 129, 40, 7, 200, 33, 33]
+    sizes = [12, 30, 64, 64, 65, 20, 128, 3, 129, 40, 7, 200, 33, 33]   # classes 1, 2, 3, 3, 4, 4, 2
     off = np.concatenate([[0], np.cumsum(sizes)])
     d = 256
     x = torch.randn(int(off[-1]), d, generator=torch.Generator().manual_seed(9)).to(device)
