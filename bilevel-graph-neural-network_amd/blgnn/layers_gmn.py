@@ -141,13 +141,15 @@ class GMNPropagator(nn.Module):
                 cur = torch.cuda.current_stream(x.device)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    ops.gmn_match(seg, x, out=f_in[:, 3 * D:], row_amax=af, max_nodes=self._max_nodes(batch_data))
+                    ops.gmn_match(seg, x, out=f_in[:, 3 * D:], row_amax=af, max_nodes=self._max_nodes(batch_data),
+                                  order=self._pair_order(batch_data, x.device))
             pq = ops.linear(x, wpq, bpq, row_amax=ax)                     # [n, 4D] = [P | Q]
             ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:], out=f_in[:, D:3 * D], row_amax=af)
             if side is not None:
                 cur.wait_stream(side)
             else:
-                ops.gmn_match(seg, x, out=f_in[:, 3 * D:], row_amax=af, max_nodes=self._max_nodes(batch_data))
+                ops.gmn_match(seg, x, out=f_in[:, 3 * D:], row_amax=af, max_nodes=self._max_nodes(batch_data),
+                                  order=self._pair_order(batch_data, x.device))
             if af is None and hid_amax is not None:
                 af = ops.row_absmax(f_in)
             hid = ops.linear(f_in, w1, b1, act=act, rowvec=ops.row_degree(csr), rowvec_w=rw, amax_out=hid_amax, row_amax=af)
