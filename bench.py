@@ -104,6 +104,10 @@ def parse():
     ap.add_argument("--no-prune-last", action="store_true",
                     help="sharded bi-level configs: compute every row of the last interaction layer, not only the rows the "
                          "rank's pairs read")
+    ap.add_argument("--no-shared-prefix", action="store_true",
+                    help="GMN configs: compute every copy of a molecule in the pair batch (the reference's batch as is) "
+                         "instead of running the layers in front of the first cross-graph attention on the distinct "
+                         "molecules")
     ap.add_argument("--no-gmn-sp", action="store_true",
                     help="GMN configs: the in-kernel operand split of blgnn_linear_h3 instead of the pre-split pipeline")
     ap.add_argument("--gmn-match-fork", choices=("message", "edge"), default=None,
@@ -585,6 +589,7 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
                              device=device, batch_size=batch, feature_transform=transform)
     flags.gmn_fused_amax = bool(getattr(args, "gmn_fused_amax", False))
     flags.gmn_sp = not getattr(args, "no_gmn_sp", False)
+    flags.gmn_shared_prefix = not getattr(args, "no_shared_prefix", False)
     flags.gmn_match_streams = int(getattr(args, "gmn_match_streams", 1))
     if getattr(args, "gmn_match_fork", None):
         flags.gmn_match_fork = args.gmn_match_fork
@@ -606,6 +611,9 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
                       is_train=False, unique_graphs=False)
         b.merge_data['merge'].csr()
         b.merge_data['merge'].segments()
+        sm = b.shared_molecules()                          # distinct molecules + row map: part of the batch, like the CSR
+        if sm is not None:
+            sm.graph.csr()
         batches.append(b)
     Nn = int(np.mean([b.merge_data['merge'].x.shape[0] for b in batches]))
     nnz = int(np.mean([b.merge_data['merge'].edge_index.shape[1] for b in batches]))
@@ -613,7 +621,9 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
     # dominant kernel: the dense transforms of the propagator (f_message / f_node GEMMs, M = all atoms)
     timer = KernelTimer()
     saved = ops.linear
-    min_rows = Nn // 2
+    min_rows = Nn // 16                                    # every GEMM over atoms (incl. the distinct-molecule ones), not the head's
+    Nu = int(np.mean([b.shared_molecules().graph.num_nodes if b.shared_molecules() is not None else
+                      b.merge_data['merge'].x.shape[0] for b in batches]))
 
     def lin_work(x, w_kn, *a, **kw):
         M, K = x.shape
@@ -653,6 +663,19 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
         elapsed, blocks = timed_blocks(run_block, min_seconds)
         preds = last[0]
         assert preds.shape[0] == batch and bool(torch.isfinite(preds).all())
+        shared_active = getattr(model.acts[1], "_blgnn_shared", None) is not None      # (too few repeats: not taken)
+        # the same steps with every copy computed (disclosure next to the headline; not the reported value)
+        other_ms = None
+        if shared_active and not args.no_extra:
+            from blgnn.config import FLAGS as live             # (set_flags copied ``flags`` into the process-wide bag)
+            live.gmn_shared_prefix = False
+            try:
+                for i in range(2):
+                    one(i)
+                counter[0] = warmup
+                other_ms = 1e3 * run_block() / steps
+            finally:
+                live.gmn_shared_prefix = True
         if want_roofline and rank == 0:
             timer.enabled = True
             for i in range(min(steps, 8)):
@@ -671,6 +694,16 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
                       "pairs_per_step": pairs_per_step, "molecule_instances_per_gpu": 2 * batch,
                       "distinct_batches_cycled": nb, "output_logits": int(preds.shape[1]),
                       "parallelism": "pair shards x%d, no collective (pairs are independent)" % world}}
+    res["config"]["shared_prefix"] = (
+        {"on": True, "distinct_atoms_per_gpu": Nu,
+         "what": "the first GIN layer and, of the first propagator, f_message, the message sum and the [x | S] columns "
+                 "of f_node's first Linear run on the distinct molecules of the pair batch (the reference's batch holds "
+                 "one copy per pair: identical rows); the attention, the u columns of that Linear (K-split, the "
+                 "distinct-molecule part gathered in the epilogue) and every later layer run on all copies.  Same "
+                 "outputs to fp32 rounding: tests/test_gpu_sp.py",
+         "ms_per_step_without": other_ms} if shared_active else
+        {"on": False, "why": "--no-shared-prefix" if not flags.gmn_shared_prefix else
+         "%d of %d atoms are distinct: not worth a replication pass" % (Nu, Nn)})
     if want_roofline and rank == 0:
         ms, work, names = timer.result()
         mult, peak = MFMA_OF[transform]

@@ -66,7 +66,7 @@ SIGNATURES = {
     "blgnn_split_rows_sp": [_p, _i64, _i32, _i32, _p, _i64, _p, _i64, _p],
     "blgnn_join_rows_sp": [_p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p],
     "blgnn_linear_sp": [_p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _i32, _p,
-                        _p, _p, _p],
+                        _p, _p, _p, _i64, _p, _i32, _p],
     "blgnn_hadamard": [_p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p],
     "blgnn_gru_gates": [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p],
     "blgnn_gmn_match": [_p, _i32, _p, _i64, _p, _i64, _i32, _p, _i32, _i32, _p, _p, _p],
@@ -74,6 +74,7 @@ SIGNATURES = {
     "blgnn_link_pred_head": [_p, _i64, _p, _p, _i32, _i32, _f32, _i32, _p, _p, _p, _i32, _i32, _p, _i64, _p],
     "blgnn_l2_normalize_rows": [_p, _i64, _p, _i64, _i32, _i32, _f32, _p],
     "blgnn_scatter_rows": [_p, _i64, _p, _p, _i64, _i32, _i32, _p],
+    "blgnn_expand_rows": [_p, _i64, _p, _i64, _p, _i64, _i64, _p],
     "blgnn_stream_create_cu_mask": [_p, _i32, _p],
     "blgnn_stream_destroy": [_p],
     "blgnn_col_reduce": [_p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, _f32, _p, _p, _p],

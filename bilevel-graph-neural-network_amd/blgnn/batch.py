@@ -15,7 +15,7 @@ import torch
 
 from .config import FLAGS
 
-__all__ = ["BatchData", "ordered_unique"]
+__all__ = ["BatchData", "SharedMolecules", "ordered_unique"]
 
 
 def ordered_unique(a):
@@ -46,6 +46,16 @@ class _Pair(object):
             self._batch._preds_host = preds.detach().cpu().numpy()     # ONE sync for the batch
         p = self._batch._preds_host[self._i]
         return float(p[0]) if p.shape[0] == 1 else p
+
+
+class SharedMolecules(object):
+    """``graph``: GraphData of the distinct molecules of a pair batch; ``row_map`` int32 [n] (device): merged atom ->
+    its row in ``graph``."""
+
+    __slots__ = ("graph", "row_map")
+
+    def __init__(self, graph, row_map):
+        self.graph, self.row_map = graph, row_map
 
 
 class BatchData(object):
@@ -135,6 +145,30 @@ class BatchData(object):
         pair_list = [_Pair(self, i) for i in range(len(batch_gids))]
         assert len(pair_list) == batch_gids.shape[0]
         return merged, pair_list
+
+    def shared_molecules(self):
+        """Pair batches (``unique_graphs=False``: src/config.py:258 for the GMN model) hold one copy of a molecule per
+        pair it occurs in.  -> ``SharedMolecules`` (the distinct molecules merged once + the row of every merged atom
+        in that graph), or None for a unique-graph batch.  Layers whose input does not yet depend on the pair partner
+        (everything in front of the first cross-graph attention) compute on the distinct molecules and replicate rows."""
+        sm = getattr(self, "_shared", None)
+        if sm is None:
+            sm = False
+            if not self.unique_graphs and self._graph_gids:
+                gids = np.asarray(self._graph_gids)
+                um = self.dataset.molecules.merge(ordered_unique(gids).tolist(), True)
+                inst_u = np.vectorize(um["gids_to_batch_ind"].get)(gids).astype(np.int64)
+                sizes = np.asarray(um["graph_sizes"], dtype=np.int64)
+                u_off = np.concatenate([[0], np.cumsum(sizes)])
+                inst_sizes = sizes[inst_u]
+                inst_off = np.concatenate([[0], np.cumsum(inst_sizes)])
+                n = int(inst_off[-1])
+                assert n == self.merge_data['merge'].x.shape[0]
+                row_map = np.repeat(u_off[inst_u] - inst_off[:-1], inst_sizes) + np.arange(n, dtype=np.int64)
+                dev = self.merge_data['merge'].x.device
+                sm = SharedMolecules(um["merge"], torch.as_tensor(row_map.astype(np.int32)).to(dev))
+            self._shared = sm
+        return sm or None
 
     def interaction_rows_of_batch_graphs(self):
         """gs_map[gid] for every graph of the merged batch, int32 on the device."""

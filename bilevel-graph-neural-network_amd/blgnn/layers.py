@@ -157,6 +157,19 @@ class NodeEmbedding(nn.Module):
             return batch_data.merge_higher_level['merge']
         return batch_data.merge_data['merge']
 
+    def _shared_molecules(self, ins, batch_data, model, pool):
+        """``batch_data.shared_molecules()`` when this call is the FIRST layer of an eval forward over a pair batch
+        (its input is the merged atom features, nothing pair-dependent yet), the duplication is worth a replication
+        pass (FLAGS.gmn_shared_prefix, default on; < 60 % distinct rows) and no readout hangs on this layer."""
+        if not getattr(FLAGS, "gmn_shared_prefix", True) or pool is not None or not hasattr(batch_data, "shared_molecules"):
+            return None
+        if model.acts is None or len(model.acts) != 1 or ins is not self._graph(batch_data).x:
+            return None
+        sm = batch_data.shared_molecules()
+        if sm is None or sm.graph.num_nodes > 0.6 * ins.shape[0]:
+            return None
+        return sm
+
     def forward(self, ins, batch_data, model, out=None):
         """``out`` (optional) lets the caller place the result in a column slice of
         a wider buffer (multi-scale readout / GMN f_node input)."""
@@ -179,6 +192,7 @@ class NodeEmbedding(nn.Module):
             fused_pool = False
             wide = None
             want_sp = False
+            shared = shared_sp = None
             if self.type == 'gin' and out is None and not self.higher_level and not self.normalize \
                     and 'gmn' in FLAGS.model:
                 # the GMNPropagator that follows reads this layer's output as the first D columns of its [n, 4D]
@@ -188,6 +202,7 @@ class NodeEmbedding(nn.Module):
                     # sp pipeline: the propagator's GEMMs read this layer's output as fp16 piece planes, written by
                     # the layer kernel's store loop next to the fp32 rows (which the attention kernel reads)
                     want_sp = True
+                    shared = self._shared_molecules(ins, batch_data, model, pool)
                 else:
                     wide = torch.empty((ins.shape[0], 4 * self.out_dim), dtype=torch.float32, device=ins.device)
                     out = wide[:, :self.out_dim]
@@ -198,6 +213,11 @@ class NodeEmbedding(nn.Module):
                 eps = self._cache.get("eps", lambda e: float(e[0]), self.conv.eps)
                 transform = getattr(FLAGS, "feature_transform", "bf16x6")
                 g = self._graph(batch_data)
+                if shared is not None:
+                    # first layer of a pair batch: the rows of a molecule are the same in every pair it occurs in
+                    # (this layer sees no cross-graph edge), so the layer runs on the distinct molecules
+                    g = shared.graph
+                    ins, csr = g.x, g.csr()
                 codes = getattr(g, "codes", None) if ins is getattr(g, "x", None) else None
                 if transform == "f16x3" and getattr(FLAGS, "categorical_input", True) and \
                         ops.gin_layer_h3_codes_supported(csr, codes, getattr(g, "code_offsets", None) or [0], self.out_dim) \
@@ -225,9 +245,11 @@ class NodeEmbedding(nn.Module):
                                          amax_out=amax, out_sp=sp_x)
                     if amax is not None:
                         x._blgnn_amax = amax
-                    if sp_x is not None:
+                    if sp_x is not None and shared is None:
                         x._blgnn_sp = f_sp
                     fused_pool = True
+                    if shared is not None:
+                        shared_sp = f_sp if sp_x is not None else None
                 elif transform in ("bf16x6", "f16x3") and \
                         ops.gin_layer_x6_supported(csr, ins, ins.shape[1], self.out_dim):
                     # dense transforms on the bf16 matrix cores at fp32 accuracy (three-piece split)
@@ -262,6 +284,12 @@ class NodeEmbedding(nn.Module):
                 plan.done.add(id(self))
             if wide is not None:
                 x._blgnn_wide = wide
+            if shared is not None:
+                # replicate: the attention (and model.acts) read one row per merged atom; the propagator that follows
+                # keeps working on the distinct molecules until its f_node input (layers_gmn.py: _forward_sp)
+                x_u = x
+                x = ops.expand_rows(x_u, shared.row_map)
+                x._blgnn_shared = (shared, x_u, shared_sp)
             model.store_layer_output(self, x)
             if self.normalize:
                 x = ops.l2_normalize_rows(x)

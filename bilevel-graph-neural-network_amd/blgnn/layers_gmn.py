@@ -95,6 +95,17 @@ class GMNPropagator(nn.Module):
         return self._cache.get("node1", compose, lin2.weight, lin2.bias, lin.weight, lin.bias, bn.weight,
                                bn.bias, bn.running_mean, bn.running_var)
 
+    def _node_weights_split(self):
+        """``_node_weights`` with the composed first Linear cut at row 3D: -> (w[:3D] for [x | S], w[3D:] for u, bias,
+        rank-1 factor).  The two row slices are kept (views of the cached matrix) so that the packed-weight cache of
+        ``ops.linear_sp`` recognises them from call to call."""
+        w1, b1, rw = self._node_weights()
+        D = self.input_dim
+        sp = getattr(self, "_w1_split", None)
+        if sp is None or sp[0] is not w1:
+            sp = self._w1_split = (w1, w1[:3 * D], w1[3 * D:])
+        return sp[1], sp[2], b1, rw
+
     def forward(self, ins, batch_data, model, edge_index=None):
         ops.require_device(ins, "ins")
         x = ins
@@ -202,10 +213,25 @@ class GMNPropagator(nn.Module):
         with torch.no_grad():
             wpq, bpq, _, _ = self._message_weights()
             w1, b1, rw = self._node_weights()
+            # First propagator of a pair batch (the producing layer ran on the distinct molecules and replicated x:
+            # layers.py ``_shared_molecules``): f_message and the message sum see no cross-graph edge either, and
+            # f_node's first Linear is linear in its input columns -- [x | S | u] @ W = [x | S] @ W[:3D] + u @ W[3D:] --
+            # so everything but the attention and the u part of that product stays on the distinct molecules; the
+            # [x | S] part reaches every copy as a gathered addend in the epilogue of the u product.
+            sh = getattr(x, "_blgnn_shared", None)
             f_sp = getattr(x, "_blgnn_sp", None)                 # the producing GIN layer wrote x's planes there
-            if f_sp is None or tuple(f_sp.shape) != (n, 4 * D):
-                f_sp = ops.SpRows(n, 4 * D, x.device)
-                ops.split_rows_sp(x, out=f_sp.cols(0, D))
+            if sh is not None:
+                shared, x_u, f_sp_u = sh
+                nu = x_u.shape[0]
+                if f_sp_u is None or tuple(f_sp_u.shape) != (nu, 4 * D):
+                    f_sp_u = ops.SpRows(nu, 4 * D, x.device)
+                    ops.split_rows_sp(x_u, out=f_sp_u.cols(0, D))
+                u_sp = ops.SpRows(n, D, x.device)
+            else:
+                if f_sp is None or tuple(f_sp.shape) != (n, 4 * D):
+                    f_sp = ops.SpRows(n, 4 * D, x.device)
+                    ops.split_rows_sp(x, out=f_sp.cols(0, D))
+                u_sp = f_sp.cols(3 * D, 4 * D)
             side = self._side_stream(x.device) if (x.is_cuda and getattr(FLAGS, "gmn_overlap_match", True)) else None
             seg = merge.segments()                               # (built on the launch stream, before the fork)
 
@@ -230,7 +256,7 @@ class GMNPropagator(nn.Module):
                     ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, classes=1 if two else 0, order=order)
                     if two:
                         side.wait_stream(side2)
-                    ops.split_rows_sp(u, out=f_sp.cols(3 * D, 4 * D))
+                    ops.split_rows_sp(u, out=u_sp)
                     u.record_stream(side)
 
             # Where the attention forks off (FLAGS.gmn_match_fork): "message" (default) = beside the message GEMM AND the
@@ -243,18 +269,31 @@ class GMNPropagator(nn.Module):
             fork = getattr(FLAGS, "gmn_match_fork", "message") if side is not None else None
             if fork == "message":
                 fork_match()
-            pq, _ = ops.linear_sp(f_sp.cols(0, D), wpq, bpq)                              # [n, 4D] = [P | Q], fp32
-            if fork == "edge":
-                fork_match()
-            ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:], out_sp=f_sp.cols(D, 3 * D))
+            if sh is not None:
+                csr_u = shared.graph.csr()
+                pq, _ = ops.linear_sp(f_sp_u.cols(0, D), wpq, bpq)                        # [nu, 4D] = [P | Q], fp32
+                if fork == "edge":
+                    fork_match()
+                ops.edge_relu_sum(csr_u, pq[:, :2 * D], pq[:, 2 * D:], out_sp=f_sp_u.cols(D, 3 * D))
+                w1a, w1b, b1, rw = self._node_weights_split()
+                part, _ = ops.linear_sp(f_sp_u.cols(0, 3 * D), w1a, b1, rowvec=ops.row_degree(csr_u), rowvec_w=rw)
+            else:
+                pq, _ = ops.linear_sp(f_sp.cols(0, D), wpq, bpq)                          # [n, 4D] = [P | Q], fp32
+                if fork == "edge":
+                    fork_match()
+                ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:], out_sp=f_sp.cols(D, 3 * D))
             if side is not None:
                 torch.cuda.current_stream(x.device).wait_stream(side)
             else:
                 ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, order=order)
-                ops.split_rows_sp(u, out=f_sp.cols(3 * D, 4 * D))
+                ops.split_rows_sp(u, out=u_sp)
             hid = ops.SpRows(n, 4 * D, x.device)
-            ops.linear_sp(f_sp, w1, b1, act=act_name(self.f_node.activation), rowvec=ops.row_degree(csr), rowvec_w=rw,
-                          out_sp=hid)
+            if sh is not None:
+                ops.linear_sp(u_sp, w1b, None, act=act_name(self.f_node.activation), addend=part,
+                              addend_rows=shared.row_map, out_sp=hid)
+            else:
+                ops.linear_sp(f_sp, w1, b1, act=act_name(self.f_node.activation), rowvec=ops.row_degree(csr),
+                              rowvec_w=rw, out_sp=hid)
             out, _ = ops.linear_sp(hid, self.f_node.weight_kn(1), self.f_node.layers[1].bias)
         model.store_layer_output(self, out)
         return out

@@ -436,10 +436,11 @@ def linear_sp_supported(M, K, N):
 
 
 def linear_sp(xs, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn_shift=None,
-              rowvec=None, rowvec_w=None, out=None, out_sp=None, f32=None):
-    """epi(X @ w_kn + bias [+ rowvec (x) rowvec_w]) with X an ``SpRows``.  The result goes to fp32 rows (``out``, or a
-    new tensor when ``f32``; default: when no ``out_sp`` is given), to ``out_sp`` (``SpRows``), or to both.
-    -> (fp32 result or None, out_sp or None)."""
+              rowvec=None, rowvec_w=None, out=None, out_sp=None, f32=None, addend=None, addend_rows=None):
+    """epi(X @ w_kn + bias [+ rowvec (x) rowvec_w] [+ addend[addend_rows]]) with X an ``SpRows``.  The result goes to
+    fp32 rows (``out``, or a new tensor when ``f32``; default: when no ``out_sp`` is given), to ``out_sp``
+    (``SpRows``), or to both.  ``addend`` fp32 [R, N] (rows picked by the int32 ``addend_rows`` [M], or row m when
+    None): the other half of a K-split product.  -> (fp32 result or None, out_sp or None)."""
     M, K = xs.shape
     if w_kn.shape[0] != K:
         raise ValueError("blgnn: x is [%d,%d] but w is [%d,%d]" % (M, K, w_kn.shape[0], w_kn.shape[1]))
@@ -450,9 +451,14 @@ def linear_sp(xs, w_kn, bias=None, act="identity", act_param=None, bn_scale=None
     if f32 or out is not None:
         y = _out(out, M, N, xs.planes)
         yp, ldy = _mat(y, "out")
+    ap, lda = (None, 0) if addend is None else _mat(addend, "addend")
+    if addend is not None and (addend.shape[1] != N or (addend_rows is None and addend.shape[0] < M) or
+                               (addend_rows is not None and addend_rows.shape[0] != M)):
+        raise ValueError("blgnn: linear_sp addend must be [R, %d] with one addend row (index) per output row" % N)
     call("blgnn_linear_sp", *_sp_args(xs, M, K), _packed_weight(w_kn, "sp").data_ptr(), yp, ldy,
          *_sp_args(out_sp, M, N), M, N, K, _vec(bias, "bias"), _vec(rowvec, "rowvec"), _vec(rowvec_w, "rowvec_w"),
-         _act(act), _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"), _stream())
+         _act(act), _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"),
+         ap, lda, _vec(addend_rows, "addend_rows", torch.int32), 0 if addend is None else addend.shape[0], _stream())
     return y, out_sp
 
 
@@ -756,6 +762,30 @@ def scatter_rows(src, row_map, dst):
     call("blgnn_scatter_rows", sp, lds, _vec(row_map, "row_map", torch.int32, False), dp, ldd,
          src.shape[0], src.shape[1], _stream())
     return dst
+
+
+def expand_rows(src, row_map, out=None):
+    """out[i] = src[row_map[i]] for 2-D tensors of any dtype (rows moved as bytes): the replication step of a pair
+    batch whose pair-independent layers ran on the distinct molecules (include/blgnn.h: blgnn_expand_rows)."""
+    require_device(src, "src")
+    if src.dim() != 2 or src.stride(1) != 1:
+        raise ValueError("blgnn: expand_rows needs 2-D rows with unit column stride")
+    n = int(row_map.shape[0])
+    if out is None:
+        out = torch.empty((n, src.shape[1]), dtype=src.dtype, device=src.device)
+    if out.dtype != src.dtype or tuple(out.shape) != (n, src.shape[1]) or out.stride(1) != 1:
+        raise ValueError("blgnn: expand_rows output must be [%d, %d] %s rows" % (n, src.shape[1], src.dtype))
+    item = src.element_size()
+    call("blgnn_expand_rows", src.data_ptr(), src.stride(0) * item, _vec(row_map, "row_map", torch.int32, False), n,
+         out.data_ptr(), out.stride(0) * item, src.shape[1] * item, _stream())
+    return out
+
+
+def expand_rows_sp(src, row_map, out):
+    """``expand_rows`` on an ``SpRows`` (column slices allowed): piece planes and scale bytes."""
+    expand_rows(src.planes, row_map, out=out.planes)
+    expand_rows(src.scales, row_map, out=out.scales)
+    return out
 
 
 # ---- backward pass / train mode (include/blgnn.h "backward pass" block) -------------------------------------

@@ -58,6 +58,8 @@ struct LinearSpArgs {
     int32_t M, N, K;
     const float *rowvec, *rowvec_w;
     Epilogue epi;
+    const float *addend; int64_t ldadd;            // optional: + addend[addend_rows ? addend_rows[m] : m, n] in front of the activation
+    const int32_t *addend_rows; int32_t n_addend;  //   (n_addend = rows of ``addend``)
 };
 
 constexpr int SP_BM = 256, SP_BN = 256, SP_BK = 32;
@@ -159,7 +161,7 @@ __global__ void __launch_bounds__(256) k_join_sp(const _Float16 *__restrict__ xs
 // and row parameters requested before the current tile's epilogue, 16-row staging passes out of the stage-1 region --
 // to hide the ~14 us of a tile's 90 that are neither main loop nor epilogue: 2 746 vs 2 591 us at K = N = 1024, 1 046 vs
 // 1 002 at K = 256: static tile assignment loses more than the hidden round trips gain.)
-template <bool GEN>
+template <bool GEN, bool ADD = false>
 __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
     extern __shared__ float4 sp_smem[];
     char *smem = reinterpret_cast<char *>(sp_smem);
@@ -242,6 +244,7 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
     unsigned long long epack[4];
     int eiu[4], eimax[4];
     float rv[4];
+    unsigned aoff[4] = {0u, 0u, 0u, 0u};                    // ADD: byte offset of this lane's four columns in its rows' addend rows
 #pragma unroll
     for (int im = 0; im < 4; ++im) {
         const int mr = m0 + wm * 64 + 16 * im + r16;
@@ -251,6 +254,7 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
         epack[im] = pk;
         eiu[im] = eimax[im] = (int)(pk & 0xffu);
         rv[im] = P.rowvec ? P.rowvec[m] : 0.f;
+        if (ADD) aoff[im] = (unsigned)(P.addend_rows ? P.addend_rows[m] : m) * (unsigned)(P.ldadd * 4) + (unsigned)kg * 16u;
     }
     float winv = *reinterpret_cast<const float *>(P.wp);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // K step 0 has landed (and the plain loads above)
@@ -260,6 +264,7 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
     for (int im = 0; im < 4; ++im) {
         unsigned lo = (unsigned)epack[im], hi = (unsigned)(epack[im] >> 32);
         asm volatile("" : "+v"(lo), "+v"(hi), "+v"(rv[im]));
+        if (ADD) asm volatile("" : "+v"(aoff[im]));
         epack[im] = ((unsigned long long)hi << 32) | lo;
     }
 #pragma unroll
@@ -346,6 +351,54 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
     for (int im = 0; im < 4; ++im) rsc[im] = __uint_as_float((unsigned)eiu[im] << 23) * winv;
     // straight-line: the staged parameters hold neutral values where the caller passed none (scale 1, shift 0,
     // rank-1 factor 0); row blocks innermost, so a column group's parameters are read once
+    if constexpr (ADD) {
+        // + addend rows (gathered by addend_rows) in front of the activation: this lane's 4 x 8 groups of four
+        // columns, fetched in four groups of two column blocks, two groups in flight (the operand fragments'
+        // registers are free now); a 16-lane quarter of a wavefront reads 64 contiguous bytes of 16 rows per request
+        const __amdgpu_buffer_rsrc_t RA = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(P.addend), 0, (int)((int64_t)(P.n_addend - 1) * P.ldadd * 4 + (int64_t)P.N * 4), 0x00020000);
+        f32x4v ad[2][2][4];
+        auto fetch = [&](int g, f32x4v (&dst)[2][4]) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int im = 0; im < 4; ++im)
+                    dst[j][im] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(
+                        RA, aoff[im], (n0 + wn * 128 + 16 * (2 * g + j)) * 4, 0));
+        };
+        fetch(0, ad[0]);
+        fetch(1, ad[1]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int jn = 2 * g + j;
+                const int nl = wn * 128 + 16 * jn + 4 * kg;
+                const float4 b4 = *reinterpret_cast<const float4 *>(cpar + nl);
+                const float4 w4 = *reinterpret_cast<const float4 *>(cpar + SP_BN + nl);
+                const float4 s4 = *reinterpret_cast<const float4 *>(cpar + 2 * SP_BN + nl);
+                const float4 t4 = *reinterpret_cast<const float4 *>(cpar + 3 * SP_BN + nl);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
+                const float sc[4] = {s4.x, s4.y, s4.z, s4.w}, sh[4] = {t4.x, t4.y, t4.z, t4.w};
+                float sl[4] = {0.f, 0.f, 0.f, 0.f};
+                if (GEN) {
+                    const float4 p4 = *reinterpret_cast<const float4 *>(cpar + 4 * SP_BN + nl);
+                    sl[0] = p4.x; sl[1] = p4.y; sl[2] = p4.z; sl[3] = p4.w;
+                }
+#pragma unroll
+                for (int im = 0; im < 4; ++im)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v = fmaf(acc[im][jn][q], rsc[im], ad[g & 1][j][im][q]);
+                        v = fmaf(rv[im], ww[q], v + bb[q]);
+                        if (GEN) v = apply_act(v, act, sl[q]);
+                        else v = (relu && !(v > 0.f)) ? 0.f : v;
+                        acc[im][jn][q] = fmaf(v, sc[q], sh[q]);
+                    }
+            }
+            if (g + 2 < 4) fetch(g + 2, ad[g & 1]);
+        }
+    } else
 #pragma unroll
     for (int jn = 0; jn < 8; ++jn) {
         const int nl = wn * 128 + 16 * jn + 4 * kg;
@@ -447,21 +500,23 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
 #endif
 }
 
-template <bool GEN>
+template <bool GEN, bool ADD = false>
 static int launch_linear_sp_t(const LinearSpArgs &P, hipStream_t s) {
     static bool declared = false;
     if (!declared) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_sp<GEN>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_sp<GEN, ADD>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS) != hipSuccess)
             return fail(BLGNN_ERR_LAUNCH, "linear_sp: cannot raise the dynamic LDS limit to %d bytes", SP_LDS);
         declared = true;
     }
     const int64_t blocks = (int64_t)((P.M + SP_BM - 1) / SP_BM) * (P.N / SP_BN);
-    hipLaunchKernelGGL(k_linear_sp<GEN>, dim3((unsigned)blocks), dim3(512), SP_LDS, s, P);
+    hipLaunchKernelGGL((k_linear_sp<GEN, ADD>), dim3((unsigned)blocks), dim3(512), SP_LDS, s, P);
     return launch_status("linear_sp");
 }
 
 static int launch_linear_sp(const LinearSpArgs &P, hipStream_t s) {
+    if (P.addend)
+        return P.epi.act <= BLGNN_ACT_RELU ? launch_linear_sp_t<false, true>(P, s) : launch_linear_sp_t<true, true>(P, s);
     return P.epi.act <= BLGNN_ACT_RELU ? launch_linear_sp_t<false>(P, s) : launch_linear_sp_t<true>(P, s);
 }
 
@@ -521,12 +576,19 @@ extern "C" int blgnn_linear_sp(const void *xs, int64_t ldxs, const uint8_t *xe, 
                                float *y, int64_t ldy, void *ys, int64_t ldys, uint8_t *ye, int64_t ldye,
                                int32_t M, int32_t N, int32_t K, const float *bias, const float *rowvec,
                                const float *rowvec_w, int32_t act, const float *act_param,
-                               const float *bn_scale, const float *bn_shift, void *stream) {
+                               const float *bn_scale, const float *bn_shift, const float *addend, int64_t ld_addend,
+                               const int32_t *addend_rows, int32_t num_addend_rows, void *stream) {
     BLGNN_CHECK_ARG(M >= 0 && N > 0 && K > 0, "linear_sp: bad sizes");
     if (M == 0) return BLGNN_OK;
-    if (N % SP_BN != 0 || K % SP_BLOCK != 0)
-        return fail(BLGNN_ERR_UNSUPPORTED, "linear_sp: needs N %% 256 == 0 and K %% 256 == 0 (got N=%d K=%d); use "
+    if (N % SP_BN != 0 || K % SP_BLOCK != 0 || K > 8 * SP_BLOCK)
+        return fail(BLGNN_ERR_UNSUPPORTED, "linear_sp: needs N %% 256 == 0, K %% 256 == 0 and K <= 2048 (got N=%d K=%d); use "
                     "blgnn_linear_h3 / blgnn_linear", N, K);
+    BLGNN_CHECK_ARG(!addend || (ld_addend >= N && ld_addend % 4 == 0 && aligned16(addend) && num_addend_rows > 0 &&
+                                (addend_rows || num_addend_rows >= M)),
+                    "linear_sp: the addend needs 16-byte aligned rows of >= N columns (and M rows without addend_rows)");
+    BLGNN_CHECK_ARG(!addend || (int64_t)num_addend_rows * ld_addend * 4 < ((int64_t)1 << 31),
+                    "linear_sp: the addend must be smaller than 2 GiB (32-bit buffer offsets)");
+    BLGNN_CHECK_ARG(addend || !addend_rows, "linear_sp: addend_rows without addend");
     BLGNN_CHECK_ARG(xs && xe && w_packed && (y || ys), "linear_sp: null pointer");
     BLGNN_CHECK_ARG(ldxs >= 2 * (int64_t)K && ldxs % 8 == 0 && aligned16(xs) && ldxe >= K / SP_BLOCK,
                     "linear_sp: bad X planes (ldxs >= 2K, 16-byte aligned rows)");
@@ -546,5 +608,6 @@ extern "C" int blgnn_linear_sp(const void *xs, int64_t ldxs, const uint8_t *xe, 
     P.y = y; P.ldy = ldy; P.ys = reinterpret_cast<_Float16 *>(ys); P.ldys = ldys; P.ye = ye; P.ldye = ldye;
     P.M = M; P.N = N; P.K = K; P.rowvec = rowvec; P.rowvec_w = rowvec_w;
     P.epi = Epilogue{bias, act_param, bn_scale, bn_shift, act};
+    P.addend = addend; P.ldadd = ld_addend; P.addend_rows = addend_rows; P.n_addend = num_addend_rows;
     return launch_linear_sp(P, (hipStream_t)stream);
 }

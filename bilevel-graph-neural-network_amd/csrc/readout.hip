@@ -115,6 +115,24 @@ k_scatter_rows(const float *__restrict__ src, int64_t lds, const int32_t *__rest
     }
 }
 
+// dst row i = src row row_map[i], rows as opaque bytes in units of U (four dwords: 16-byte aligned rows; else bytes).  One
+// thread per unit, consecutive threads on consecutive units of a row: reads of a source row repeat (every molecule of a
+// pair batch occurs ~5 times) and hit in L2, the writes stream.
+typedef unsigned int expand_u4 __attribute__((ext_vector_type(4)));
+
+template <typename U>
+__global__ void __launch_bounds__(256)
+k_expand_rows(const char *__restrict__ src, int64_t lds, const int32_t *__restrict__ row_map, char *__restrict__ dst,
+              int64_t ldd, int64_t rows, int32_t upr) {
+    const int64_t total = rows * upr;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / upr;
+        const int c = (int)(idx - r * upr);
+        const U v = *reinterpret_cast<const U *>(src + (int64_t)row_map[r] * lds + (int64_t)c * sizeof(U));
+        __builtin_nontemporal_store(v, reinterpret_cast<U *>(dst + r * ldd + (int64_t)c * sizeof(U)));
+    }
+}
+
 }  // namespace blgnn
 
 using namespace blgnn;
@@ -197,4 +215,25 @@ extern "C" int blgnn_scatter_rows(const float *src, int64_t lds, const int32_t *
     hipLaunchKernelGGL(k_scatter_rows, dim3(wave_grid(G)), dim3(256), 0, (hipStream_t)stream, src, lds,
                        row_map, dst, ldd, G, d);
     return launch_status("scatter_rows");
+}
+
+extern "C" int blgnn_expand_rows(const void *src, int64_t ld_src, const int32_t *row_map, int64_t num_rows, void *dst,
+                                 int64_t ld_dst, int64_t row_bytes, void *stream) {
+    BLGNN_CHECK_ARG(num_rows >= 0 && row_bytes >= 0, "expand_rows: negative size");
+    if (num_rows == 0 || row_bytes == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(src && dst && row_map && ld_src >= row_bytes && ld_dst >= row_bytes, "expand_rows: bad args");
+    BLGNN_CHECK_ARG(row_bytes <= (1 << 24), "expand_rows: rows of at most 16 MiB");
+    const bool wide = row_bytes % 16 == 0 && ld_src % 16 == 0 && ld_dst % 16 == 0 && aligned16(src) && aligned16(dst);
+    const int upr = (int)(wide ? row_bytes / 16 : row_bytes);
+    int64_t blocks = (num_rows * upr + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (wide)
+        hipLaunchKernelGGL(k_expand_rows<expand_u4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const char *>(src), ld_src, row_map, reinterpret_cast<char *>(dst), ld_dst,
+                           num_rows, upr);
+    else
+        hipLaunchKernelGGL(k_expand_rows<unsigned char>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const char *>(src), ld_src, row_map, reinterpret_cast<char *>(dst), ld_dst,
+                           num_rows, upr);
+    return launch_status("expand_rows");
 }

@@ -382,7 +382,11 @@ int blgnn_linear_h3(const float *x, int64_t ldx, const float *row_amax, const vo
  * blgnn_linear_sp: epi(X @ W + bias + rowvec (x) rowvec_w) as three fp16 MFMA products per fp32 product
  * (fp32-equivalent, see blgnn_linear_h3), 256 x 256 tiles, both operands by LDS-DMA.  The result goes to
  * y (fp32 rows, ldy % 4 == 0), to ys / ye (sp format) or to both; pass NULL for the one not wanted.
- * Needs N % 256 == 0 and K % 256 == 0 (K <= 2048); other shapes: BLGNN_ERR_UNSUPPORTED (use blgnn_linear_h3). */
+ * Needs N % 256 == 0 and K % 256 == 0 (K <= 2048); other shapes: BLGNN_ERR_UNSUPPORTED (use blgnn_linear_h3).
+ * addend (optional, fp32 rows of >= N columns, < 2 GiB): epi(X @ W + bias + rowvec (x) rowvec_w + addend[r(m), :]) with
+ * r(m) = addend_rows[m] (int32 [M], rows of addend: num_addend_rows) or m -- the K-split of a GEMM whose leading
+ * input columns repeat across rows: f_node's first Linear on [x | S | u] in the first propagator of a pair batch,
+ * where [x | S] @ W[:3D] is computed once per distinct molecule (blgnn_expand_rows) and u @ W[3D:] for every atom. */
 int64_t blgnn_packed_weight_sp_elems(int32_t K, int32_t N);
 int blgnn_pack_weight_sp(const float *w, int64_t ldw, int32_t K, int32_t N, void *out, void *stream);
 int blgnn_split_rows_sp(const float *x, int64_t ldx, int32_t M, int32_t K, void *xs, int64_t ldxs,
@@ -393,7 +397,8 @@ int blgnn_linear_sp(const void *xs, int64_t ldxs, const uint8_t *xe, int64_t ldx
                     float *y, int64_t ldy, void *ys, int64_t ldys, uint8_t *ye, int64_t ldye,
                     int32_t M, int32_t N, int32_t K, const float *bias, const float *rowvec,
                     const float *rowvec_w, int32_t act, const float *act_param,
-                    const float *bn_scale, const float *bn_shift, void *stream);
+                    const float *bn_scale, const float *bn_shift, const float *addend, int64_t ld_addend,
+                    const int32_t *addend_rows, int32_t num_addend_rows, void *stream);
 
 /* ---- GMN cross-graph attention ------------------------------------------ */
 
@@ -456,6 +461,15 @@ int blgnn_l2_normalize_rows(const float *x, int64_t ldx, float *y, int64_t ldy,
  * is not a plain segment reduce). */
 int blgnn_scatter_rows(const float *src, int64_t lds, const int32_t *row_map,
                        float *dst, int64_t ldd, int32_t G, int32_t d, void *stream);
+
+/* dst row i = src row row_map[i] for i < num_rows; rows are opaque bytes (row_bytes each; leading dimensions in
+ * BYTES).  The replication step of a pair batch: src/batch.py:105-144 with batch_unique_graphs = False
+ * (src/config.py:258) appends a molecule's tensors once per pair it occurs in, so every layer in front of the first
+ * cross-graph attention computes identical rows ~(2 * pairs / distinct drugs) times; here those layers run on the
+ * distinct molecules and their results (fp32 rows, sp piece planes, sp scale bytes) are replicated by this call.
+ * 16-byte units when row_bytes, both leading dimensions and both pointers are multiples of 16, bytes otherwise. */
+int blgnn_expand_rows(const void *src, int64_t ld_src, const int32_t *row_map, int64_t num_rows,
+                      void *dst, int64_t ld_dst, int64_t row_bytes, void *stream);
 
 /* ---- backward pass / train mode (src/train.py:177-182) -------------------- */
 /* The large products of the backward pass are the forward entry points on other operands:

@@ -78,6 +78,36 @@ def test_linear_sp(device, M, K, N, act):
     assert torch.equal(widey[:, 4:4 + N], y) and float(widey[:, :4].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,K,N,act,mapped", [(700, 256, 1024, "relu", True), (515, 512, 256, "identity", True),
+                                              (300, 256, 512, "relu", False), (257, 256, 256, "tanh", True)])
+def test_linear_sp_addend(device, M, K, N, act, mapped):
+    """the K-split epilogue: epi(X @ W + bias + rowvec (x) rowvec_w + addend[rows]) == fp64 with the addend gathered
+    by a row map (few distinct rows, repeated and unordered) or row for row; addend rows wider than N (a column
+    slice); sp and fp32 outputs; ragged M"""
+    g = torch.Generator().manual_seed(M + K + N + 1)
+    R = 90 if mapped else M
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(K, N, generator=g) / K ** 0.5
+    b, rv, rw = torch.randn(N, generator=g) * 0.1, torch.rand(M, generator=g) * 3, torch.randn(N, generator=g) * 0.1
+    scale, shift = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    addw = torch.randn(R, N + 12, generator=g) * 2
+    rows = torch.randint(0, R, (M,), generator=g).to(torch.int32) if mapped else None
+    D = lambda t: t.double()
+    add = D(addw[:, 4:4 + N])
+    ref = D(x) @ D(w) + D(b) + D(rv).view(-1, 1) * D(rw).view(1, -1) + (add[rows.long()] if mapped else add)
+    ref = oracle.apply_act(ref, act, None) * D(scale) + D(shift)
+    dv = lambda t: t.to(device)
+    xs = ops.split_rows_sp(dv(x))
+    out_sp = ops.SpRows(M, N, device)
+    y, _ = ops.linear_sp(xs, dv(w), dv(b), act=act, bn_scale=dv(scale), bn_shift=dv(shift), rowvec=dv(rv), rowvec_w=dv(rw),
+                         out_sp=out_sp, f32=True, addend=dv(addw)[:, 4:4 + N], addend_rows=dv(rows) if mapped else None)
+    assert max_err(y, ref) < TOL
+    assert max_err(ops.join_rows_sp(out_sp), ref) < TOL
+    with pytest.raises(ValueError):                                   # one addend row (index) per output row
+        ops.linear_sp(xs, dv(w), addend=dv(addw)[:M // 2, 4:4 + N].contiguous() if not mapped else dv(addw)[:, 4:4 + N],
+                      addend_rows=dv(rows)[:-1] if mapped else None)
+
+
 @pytest.mark.parametrize("xs,ws", [(1e-6, 1.0), (3e4, 1.0), (1.0, 1e-5), (1.0, 300.0), (1e5, 1e-4), (1e-20, 1e10)])
 def test_linear_sp_range(device, xs, ws):
     """block scales inside one accumulator: tiny / huge activations and weights, rows and blocks of very different
@@ -166,3 +196,69 @@ def test_gmn_model_with_sp_pipeline_forced(device, d, shape, dataset, edge_types
     finally:
         blgnn.make_flags = orig
     assert preds.shape[0] == pairs
+
+
+def test_expand_rows_moves_bytes(device):
+    """blgnn_expand_rows: out[i] = src[row_map[i]] bit for bit -- fp32 rows, a column slice of fp16 piece planes
+    (16-byte units, strided rows), 3 of 8 scale bytes per row (byte units), repeated and unordered source rows"""
+    g = torch.Generator().manual_seed(11)
+    nu, n = 333, 2100
+    row_map = torch.randint(0, nu, (n,), generator=g).to(torch.int32).to(device)
+    idx = row_map.long()
+    x = torch.randn(nu, 256, generator=g).to(device)
+    assert torch.equal(ops.expand_rows(x, row_map), x.index_select(0, idx))
+    src, dst = ops.SpRows(nu, 1024, device), ops.SpRows(n, 1024, device)
+    src.planes.copy_(torch.randn(nu, 2048, generator=g).to(device).half())
+    src.scales.copy_(torch.randint(0, 255, (nu, 4), generator=g).to(torch.uint8).to(device))
+    dst.planes.zero_()
+    dst.scales.fill_(7)
+    ops.expand_rows_sp(src.cols(0, 768), row_map, dst.cols(0, 768))
+    assert torch.equal(dst.planes[:, :1536], src.planes[:, :1536].index_select(0, idx))
+    assert torch.equal(dst.scales[:, :3], src.scales[:, :3].index_select(0, idx))
+    assert float(dst.planes[:, 1536:].abs().max()) == 0.0 and bool((dst.scales[:, 3] == 7).all())   # the u block: untouched
+    odd = torch.randn(nu, 13, generator=g).to(device)                 # 52-byte rows: the byte path
+    assert torch.equal(ops.expand_rows(odd, row_map), odd.index_select(0, idx))
+    with pytest.raises(ValueError):
+        ops.expand_rows(x, row_map, out=torch.empty(n, 128, device=device))
+
+
+@pytest.mark.parametrize("d", [256, 512])
+def test_gmn_shared_prefix_equals_the_replicated_computation(device, d):
+    """pair batch with every molecule in ~7 pairs: the first GIN layer and the first propagator's message half run on
+    the distinct molecules (FLAGS.gmn_shared_prefix, default) -- every layer output must equal the forward that
+    computes each copy (the reference's batch: src/batch.py:105-144 with batch_unique_graphs=False): the GIN layer
+    bit for bit at d=256, everything behind it to fp32 rounding (K-split sum of f_node's first Linear)"""
+    from helpers import build
+    from test_gpu_configs import _pairs
+    ds = blgnn.make_synthetic(90, 1200, shape="drugcombo", seed=5, device=device, num_edge_types=2)
+    flags = blgnn.make_flags("lower_level_gmn", dataset="drugcombo", lower_level_gnn_type="gin", D_lower=d,
+                             device=device, gmn_sp="force")
+    model, data = build(flags, ds, seed=6, num_hyper_edge_feat=3)
+    bd = blgnn.BatchData(_pairs(ds, 320), ds, is_train=False, unique_graphs=False)
+    sm = bd.shared_molecules()
+    n = bd.merge_data['merge'].x.shape[0]
+    assert sm is not None and sm.graph.num_nodes < 0.3 * n
+    assert torch.equal(sm.graph.x.index_select(0, sm.row_map.long()), bd.merge_data['merge'].x)
+
+    from blgnn.config import FLAGS
+
+    def run(shared):
+        FLAGS.gmn_shared_prefix = shared
+        model.acts = [bd.merge_data['merge'].x]
+        for layer in model.layers[:-1]:
+            model.acts.append(layer(model.acts[-1], bd, model))
+        torch.cuda.synchronize()
+        return list(model.acts[1:])
+    a = run(True)
+    assert getattr(a[0], "_blgnn_shared", None) is not None        # the path under test was taken
+    b = run(False)
+    assert getattr(b[0], "_blgnn_shared", None) is None
+    for k, (u, v) in enumerate(zip(a, b)):
+        if d == 256 and k == 0:
+            # the fused GIN layer: a row's result does not depend on the other rows of the launch
+            assert torch.equal(u, v), "layer %d differs" % k
+        else:
+            # from the first propagator on: f_node's first Linear is summed as [x | S] @ W[:3D] + u @ W[3D:] instead of
+            # one chain over 4D columns (and at d=512 the unfused GIN layer's GEMMs pick their tile shape by the number
+            # of rows): equal to fp32 rounding, not bit for bit
+            assert max_err(u, v.cpu()) < 0.1 * TOL, "layer %d differs" % k

@@ -57,6 +57,29 @@ def test_batchdata_unique_order_and_fields():
         BatchData(np.asarray([[a, b]]), ds, is_train=False)
 
 
+def test_shared_molecules_of_a_pair_batch():
+    """pair batch (src/config.py:258: batch_unique_graphs=False) -> the distinct molecules merged once in order of
+    first appearance + the row map that reproduces every copy's rows, edges and graph ids"""
+    ds = blgnn.make_synthetic(20, 60, seed=4, device="cpu")
+    set_flags(blgnn.make_flags("lower_level_gnn", device="cpu"))
+    pairs = np.asarray([[7, 3], [3, 9], [7, 1], [9, 7]])
+    bd = BatchData(pairs, ds, is_train=False, ignore_pairs=True, unique_graphs=False)
+    sm = bd.shared_molecules()
+    assert sm is bd.shared_molecules()                            # built once per batch
+    m, u = bd.merge_data["merge"], sm.graph
+    assert u.num_graphs == 4 and sm.row_map.dtype == torch.int32 and sm.row_map.shape[0] == m.x.shape[0]
+    rm = sm.row_map.long()
+    assert torch.equal(u.x.index_select(0, rm), m.x)
+    # graph ids: copy k of the batch is distinct molecule [7, 3, 9, 1].index(gid_k)
+    first = {7: 0, 3: 1, 9: 2, 1: 3}
+    want = torch.as_tensor([first[g] for g in bd._graph_gids])[m.batch]
+    assert torch.equal(u.batch[rm], want)
+    # edges: mapping both ends of every merged edge lands on an edge of the distinct graph
+    key = lambda ei, n: set((ei[0] * n + ei[1]).tolist())
+    assert key(rm[m.edge_index], u.num_nodes) == key(u.edge_index, u.num_nodes)
+    assert BatchData(pairs, ds, is_train=False, ignore_pairs=True).shared_molecules() is None    # unique-graph batch
+
+
 def test_negative_sampling_rules():
     ds = blgnn.make_synthetic(40, 150, seed=6, device="cpu")
     flags = blgnn.make_flags("lower_level_gnn", device="cpu")
