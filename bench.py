@@ -628,7 +628,7 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
     def lin_work(x, w_kn, *a, **kw):
         M, K = x.shape
         N = w_kn.shape[1]
-        return (2.0 * M * N * K, 4.0 * M * (K + N) + 4.0 * K * N)
+        return (2.0 * M * N * K, 4.0 * M * (K + N) + 4.0 * K * N, (int(M), int(K), int(N)))
     ops.linear = timer.wrap(transform, saved, lin_work, lambda x, w_kn, *a, **kw: x.shape[0] >= min_rows)
     # the pre-split pipeline (default at these sizes): same products, operands in the sp format (4 B per element too)
     saved_sp = ops.linear_sp
@@ -719,6 +719,16 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
                      "fp16 piece planes written by the producers' epilogues, act/BN epilogue)")
             tag = "linear_sp"
         res["roofline"] = roofline_of(kname, ms, work, mult, peak, pmc_traffic(tag + "_cfg%d" % cfg_id))
+        # the same launches by GEMM shape (the step runs three to five): M x K x N, executed fp16 MFMA flops over the peak
+        shapes = {}
+        for t, w in zip(ms, work):
+            M, K, N = w[2]
+            e = shapes.setdefault(("all atoms" if M >= Nn // 2 else "distinct molecules", K, N), [0, 0.0, 0.0, 0])
+            e[0] += 1; e[1] += t; e[2] += w[0]; e[3] += M
+        res["roofline"]["by_shape"] = [
+            {"rows": k[0], "M": v[3] // v[0], "K": k[1], "N": k[2], "launches": v[0], "avg_us": round(1e3 * v[1] / v[0], 1),
+             "executed_mfma_frac": round(mult * v[2] / (v[1] * 1e-3) / 1e12 / peak, 4)}
+            for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])]
     res["_cpu"] = lambda seconds: cpu_baseline_gmn(ds, flags, model, batch, seconds, seed)
     return res
 
