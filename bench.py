@@ -108,6 +108,9 @@ def parse():
                     help="GMN configs: compute every copy of a molecule in the pair batch (the reference's batch as is) "
                          "instead of running the layers in front of the first cross-graph attention on the distinct "
                          "molecules")
+    ap.add_argument("--no-pooled-tail", action="store_true",
+                    help="GMN configs: write every propagator's node rows and run the readout as its own launch instead of "
+                         "pooling in the GEMM epilogues (and the last second Linear per graph)")
     ap.add_argument("--no-gmn-sp", action="store_true",
                     help="GMN configs: the in-kernel operand split of blgnn_linear_h3 instead of the pre-split pipeline")
     ap.add_argument("--gmn-match-fork", choices=("message", "edge"), default=None,
@@ -590,6 +593,7 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
     flags.gmn_fused_amax = bool(getattr(args, "gmn_fused_amax", False))
     flags.gmn_sp = not getattr(args, "no_gmn_sp", False)
     flags.gmn_shared_prefix = not getattr(args, "no_shared_prefix", False)
+    flags.gmn_pooled_tail = not getattr(args, "no_pooled_tail", False)
     flags.gmn_match_streams = int(getattr(args, "gmn_match_streams", 1))
     if getattr(args, "gmn_match_fork", None):
         flags.gmn_match_fork = args.gmn_match_fork
@@ -664,18 +668,21 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
         preds = last[0]
         assert preds.shape[0] == batch and bool(torch.isfinite(preds).all())
         shared_active = getattr(model.acts[1], "_blgnn_shared", None) is not None      # (too few repeats: not taken)
-        # the same steps with every copy computed (disclosure next to the headline; not the reported value)
+        pooled_active = getattr(model.acts[-3], "_blgnn_pooled", None) is not None     # (the last propagator's output)
+        # the same steps on the plain path -- every copy of a molecule computed, node rows of every layer written and a
+        # separate readout (disclosure next to the headline; not the reported value)
         other_ms = None
-        if shared_active and not args.no_extra:
+        if (shared_active or pooled_active) and not args.no_extra:
             from blgnn.config import FLAGS as live             # (set_flags copied ``flags`` into the process-wide bag)
-            live.gmn_shared_prefix = False
+            keep = (live.gmn_shared_prefix, live.gmn_pooled_tail)
+            live.gmn_shared_prefix = live.gmn_pooled_tail = False
             try:
                 for i in range(2):
                     one(i)
                 counter[0] = warmup
                 other_ms = 1e3 * run_block() / steps
             finally:
-                live.gmn_shared_prefix = True
+                live.gmn_shared_prefix, live.gmn_pooled_tail = keep
         if want_roofline and rank == 0:
             timer.enabled = True
             for i in range(min(steps, 8)):
@@ -700,10 +707,17 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
                  "of f_node's first Linear run on the distinct molecules of the pair batch (the reference's batch holds "
                  "one copy per pair: identical rows); the attention, the u columns of that Linear (K-split, the "
                  "distinct-molecule part gathered in the epilogue) and every later layer run on all copies.  Same "
-                 "outputs to fp32 rounding: tests/test_gpu_sp.py",
-         "ms_per_step_without": other_ms} if shared_active else
+                 "outputs to fp32 rounding: tests/test_gpu_sp.py"} if shared_active else
         {"on": False, "why": "--no-shared-prefix" if not flags.gmn_shared_prefix else
          "%d of %d atoms are distinct: not worth a replication pass" % (Nu, Nn)})
+    res["config"]["pooled_readout"] = (
+        {"on": True,
+         "what": "the mean readout is accumulated in the epilogue of the GEMM that produces the pooled rows; for the last "
+                 "propagator that is f_node's FIRST Linear -- its second Linear has no activation behind it and commutes "
+                 "with the mean, so it runs on one row per graph and the layer's node rows are never written.  Same "
+                 "readout to fp32 rounding: tests/test_gpu_sp.py"} if pooled_active else
+        {"on": False, "why": "--no-pooled-tail" if not flags.gmn_pooled_tail else "readout / path not eligible"})
+    res["config"]["ms_per_step_plain_path"] = other_ms       # both restructurings off (FLAGS.gmn_shared_prefix / gmn_pooled_tail)
     if want_roofline and rank == 0:
         ms, work, names = timer.result()
         mult, peak = MFMA_OF[transform]

@@ -66,7 +66,7 @@ SIGNATURES = {
     "blgnn_split_rows_sp": [_p, _i64, _i32, _i32, _p, _i64, _p, _i64, _p],
     "blgnn_join_rows_sp": [_p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p],
     "blgnn_linear_sp": [_p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _i32, _p,
-                        _p, _p, _p, _i64, _p, _i32, _p],
+                        _p, _p, _p, _i64, _p, _i32, _p, _p, _p, _i64, _i32, _p],
     "blgnn_hadamard": [_p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p],
     "blgnn_gru_gates": [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p],
     "blgnn_gmn_match": [_p, _i32, _p, _i64, _p, _i64, _i32, _p, _i32, _i32, _p, _p, _p],

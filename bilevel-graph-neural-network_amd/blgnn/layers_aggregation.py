@@ -78,7 +78,10 @@ class NodeAggregationPairs(nn.Module):
                     xs = model.acts[1:]
                 else:
                     xs = [x for i, x in enumerate(model.acts[1:]) if i % 2 == 1]
-                if isinstance(self.agg_func, _SegmentPool) and len(xs) <= 8:
+                if any(getattr(x, "_blgnn_pooled", None) is not None or getattr(x, "_blgnn_pool_of", None) is not None
+                       for x in xs):
+                    out = self._concat_with_pooled(xs, seg, out)
+                elif isinstance(self.agg_func, _SegmentPool) and len(xs) <= 8:
                     out = ops.segment_reduce_multi(seg, xs, self.agg_func.kind, out=out)
                 elif isinstance(self.agg_func, _SegmentPool):
                     G = seg.numel() - 1
@@ -90,8 +93,43 @@ class NodeAggregationPairs(nn.Module):
                         c += w
                 else:
                     out = torch.cat([self.agg_func(x, seg) for x in xs], dim=1)
+            elif getattr(ins, "_blgnn_pooled", None) is not None:
+                out = self._concat_with_pooled([ins], seg, out)
             else:
                 out = self.agg_func(ins, seg)
+        return out
+
+    def _concat_with_pooled(self, xs, seg, out):
+        """Readout when the last propagator already pooled its rows (layers_gmn.py ``_readout_of``: its [G, D] result
+        carries ``_blgnn_pooled``): node-row inputs are reduced in runs, pooled inputs copied into their columns."""
+        kind = self.agg_func.kind
+        G = seg.numel() - 1
+        widths = [x.shape[1] for x in xs]
+        if out is None:
+            out = torch.empty((G, sum(widths)), dtype=torch.float32, device=xs[0].device)
+        def pooled_of(x):
+            """-> (kind, [G, D]) when ``x`` is already pooled (``_blgnn_pooled``) or brings its pooled rows along
+            (``_blgnn_pool_of``: node rows whose producing GEMM pooled them in its epilogue), else None"""
+            tag = getattr(x, "_blgnn_pooled", None)
+            return (tag, x) if tag is not None else getattr(x, "_blgnn_pool_of", None)
+
+        c = k = 0
+        while k < len(xs):
+            have = pooled_of(xs[k])
+            if have is not None:
+                if have[0] != kind or have[1].shape[0] != G:
+                    raise ValueError("blgnn: pooled layer output does not match this readout")
+                out[:, c:c + widths[k]].copy_(have[1])                      # (placement: data movement only)
+                c += widths[k]
+                k += 1
+                continue
+            run = k
+            while run < len(xs) and run - k < 8 and pooled_of(xs[run]) is None:
+                run += 1
+            w = sum(widths[k:run])
+            ops.segment_reduce_multi(seg, xs[k:run], kind, out=out[:, c:c + w])
+            c += w
+            k = run
         return out
 
 

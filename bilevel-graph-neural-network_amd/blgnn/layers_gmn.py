@@ -287,16 +287,64 @@ class GMNPropagator(nn.Module):
             else:
                 ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, order=order)
                 ops.split_rows_sp(u, out=u_sp)
+            act = act_name(self.f_node.activation)
+            kind, last = self._readout_of(model)
+            tail = kind if (last and sh is None and act in ("relu", "identity")) else None
+            if tail is not None:
+                # LAST propagator in front of a mean / sum readout (model/layers_aggregation.py:16-19,32-41): the second
+                # Linear of f_node has no activation behind it, so it commutes with the readout --
+                # pool(hid @ W + b) = pool(hid) @ W + b -- and the hidden rows are pooled in the epilogue of the GEMM
+                # that produces them: neither they nor the layer's node rows are ever written, the second Linear runs
+                # on one row per graph.
+                G = seg.numel() - 1
+                pooled_hid = torch.zeros((G, 4 * D), dtype=torch.float32, device=x.device)
+                ops.linear_sp(f_sp, w1, b1, act=act, rowvec=ops.row_degree(csr), rowvec_w=rw,
+                              pool=(merge.row_graph(), seg, pooled_hid, tail), f32=False)
+                sizes = (seg[1:] - seg[:-1]).to(torch.float32)              # (index arithmetic on the segment table)
+                scale = sizes if tail == "sum" else (sizes > 0).to(torch.float32)
+                out = ops.linear(pooled_hid, self.f_node.weight_kn(1), None, rowvec=scale.contiguous(),
+                                 rowvec_w=self.f_node.layers[1].bias)
+                out._blgnn_pooled = tail                                    # [G, D]: the readout takes it as is
+                model.store_layer_output(self, out)
+                return out
             hid = ops.SpRows(n, 4 * D, x.device)
             if sh is not None:
-                ops.linear_sp(u_sp, w1b, None, act=act_name(self.f_node.activation), addend=part,
-                              addend_rows=shared.row_map, out_sp=hid)
+                ops.linear_sp(u_sp, w1b, None, act=act, addend=part, addend_rows=shared.row_map, out_sp=hid)
             else:
-                ops.linear_sp(f_sp, w1, b1, act=act_name(self.f_node.activation), rowvec=ops.row_degree(csr),
-                              rowvec_w=rw, out_sp=hid)
-            out, _ = ops.linear_sp(hid, self.f_node.weight_kn(1), self.f_node.layers[1].bias)
+                ops.linear_sp(f_sp, w1, b1, act=act, rowvec=ops.row_degree(csr), rowvec_w=rw, out_sp=hid)
+            if kind is not None:
+                # an earlier propagator under a multi-scale mean / sum readout: its node rows feed the next layer AND the
+                # readout -- the second Linear's epilogue pools them on the way out (the readout then copies [G, D])
+                pooled = torch.zeros((seg.numel() - 1, D), dtype=torch.float32, device=x.device)
+                out, _ = ops.linear_sp(hid, self.f_node.weight_kn(1), self.f_node.layers[1].bias,
+                                       pool=(merge.row_graph(), seg, pooled, kind), f32=True)
+                out._blgnn_pool_of = (kind, pooled)
+            else:
+                out, _ = ops.linear_sp(hid, self.f_node.weight_kn(1), self.f_node.layers[1].bias)
         model.store_layer_output(self, out)
         return out
+
+    def _readout_of(self, model):
+        """-> (kind, last): ``kind`` = "mean" | "sum" when the readout of ``model.layers`` is a plain mean / sum pooling of
+        a lower-level-only model that reads THIS propagator's output (the layer right behind the last propagator; with
+        ``concat_multi_scale`` every propagator's output), else None; ``last`` = this is the last propagator, i.e.
+        nothing but that readout reads its node rows (the reference's ``get_layer_output`` has no caller, ``model.acts``
+        is read by the readout alone).  FLAGS.gmn_pooled_tail = False: (None, False), node rows and a separate readout."""
+        if not getattr(FLAGS, "gmn_pooled_tail", True) or getattr(FLAGS, "higher_level_layers", False):
+            return None, False
+        layers = list(getattr(model, "layers", []))
+        at = [k for k, l in enumerate(layers) if l is self]
+        if len(at) != 1 or model.acts is None or len(model.acts) != at[0] + 1:
+            return None, False                              # (not driven layer by layer over model.layers)
+        from .layers_aggregation import NodeAggregationPairs, _SegmentPool
+        props = [k for k, l in enumerate(layers) if isinstance(l, GMNPropagator)]
+        nxt = layers[props[-1] + 1] if props[-1] + 1 < len(layers) else None
+        if not isinstance(nxt, NodeAggregationPairs) or not isinstance(nxt.agg_func, _SegmentPool):
+            return None, False
+        last = at[0] == props[-1]
+        if not last and not nxt.concat_multi_scale:
+            return None, False
+        return nxt.agg_func.kind, last
 
     def _forward_gru(self, x, csr, merge, model):
         """f_node='GRU' (model/layers_gmn.py:27-30,48-50; non-default): out = GRUCell(cat(m_sum, u_sum), x).  The

@@ -436,29 +436,40 @@ def linear_sp_supported(M, K, N):
 
 
 def linear_sp(xs, w_kn, bias=None, act="identity", act_param=None, bn_scale=None, bn_shift=None,
-              rowvec=None, rowvec_w=None, out=None, out_sp=None, f32=None, addend=None, addend_rows=None):
+              rowvec=None, rowvec_w=None, out=None, out_sp=None, f32=None, addend=None, addend_rows=None, pool=None):
     """epi(X @ w_kn + bias [+ rowvec (x) rowvec_w] [+ addend[addend_rows]]) with X an ``SpRows``.  The result goes to
     fp32 rows (``out``, or a new tensor when ``f32``; default: when no ``out_sp`` is given), to ``out_sp``
     (``SpRows``), or to both.  ``addend`` fp32 [R, N] (rows picked by the int32 ``addend_rows`` [M], or row m when
-    None): the other half of a K-split product.  -> (fp32 result or None, out_sp or None)."""
+    None): the other half of a K-split product.  ``pool`` = (row_graph int32 [M], seg int32 [G + 1], pooled fp32
+    [G, >= N] zeroed by the caller, "sum" | "mean"): the node -> graph readout of the result, accumulated in the epilogue
+    (with ``f32=False`` and no ``out_sp`` the rows themselves are not written).  -> (fp32 result or None, out_sp or None)."""
     M, K = xs.shape
     if w_kn.shape[0] != K:
         raise ValueError("blgnn: x is [%d,%d] but w is [%d,%d]" % (M, K, w_kn.shape[0], w_kn.shape[1]))
     N = w_kn.shape[1]
     if f32 is None:
-        f32 = out_sp is None
+        f32 = out_sp is None and pool is None
     y, yp, ldy = None, None, 0
     if f32 or out is not None:
         y = _out(out, M, N, xs.planes)
         yp, ldy = _mat(y, "out")
     ap, lda = (None, 0) if addend is None else _mat(addend, "addend")
+    pool_args = (None, None, None, 0, 0)
+    if pool is not None:
+        row_graph, seg, pooled, kind = pool
+        if row_graph.shape[0] != M or pooled.shape[1] < N or pooled.shape[0] != seg.numel() - 1:
+            raise ValueError("blgnn: linear_sp pool needs row_graph [M], seg [G + 1] and pooled [G, >= N]")
+        pp, ldp = _mat(pooled, "pooled")
+        pool_args = (_vec(row_graph, "row_graph", torch.int32, False), _vec(seg, "seg", torch.int32, False), pp, ldp,
+                     REDUCE_MEAN if kind == "mean" else REDUCE_SUM)
     if addend is not None and (addend.shape[1] != N or (addend_rows is None and addend.shape[0] < M) or
                                (addend_rows is not None and addend_rows.shape[0] != M)):
         raise ValueError("blgnn: linear_sp addend must be [R, %d] with one addend row (index) per output row" % N)
     call("blgnn_linear_sp", *_sp_args(xs, M, K), _packed_weight(w_kn, "sp").data_ptr(), yp, ldy,
          *_sp_args(out_sp, M, N), M, N, K, _vec(bias, "bias"), _vec(rowvec, "rowvec"), _vec(rowvec_w, "rowvec_w"),
          _act(act), _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"),
-         ap, lda, _vec(addend_rows, "addend_rows", torch.int32), 0 if addend is None else addend.shape[0], _stream())
+         ap, lda, _vec(addend_rows, "addend_rows", torch.int32), 0 if addend is None else addend.shape[0],
+         *pool_args, _stream())
     return y, out_sp
 
 

@@ -60,6 +60,9 @@ struct LinearSpArgs {
     Epilogue epi;
     const float *addend; int64_t ldadd;            // optional: + addend[addend_rows ? addend_rows[m] : m, n] in front of the activation
     const int32_t *addend_rows; int32_t n_addend;  //   (n_addend = rows of ``addend``)
+    // optional fused node -> graph readout of the RESULT (model/layers_aggregation.py:16-19,32-41):
+    // pool[row_graph[m], n] += y[m, n] * (pool_mean ? 1 / rows of that graph : 1); rows sorted by graph
+    const int32_t *row_graph, *seg; float *pool; int64_t ldp; int32_t pool_mean;
 };
 
 constexpr int SP_BM = 256, SP_BN = 256, SP_BK = 32;
@@ -161,7 +164,7 @@ __global__ void __launch_bounds__(256) k_join_sp(const _Float16 *__restrict__ xs
 // and row parameters requested before the current tile's epilogue, 16-row staging passes out of the stage-1 region --
 // to hide the ~14 us of a tile's 90 that are neither main loop nor epilogue: 2 746 vs 2 591 us at K = N = 1024, 1 046 vs
 // 1 002 at K = 256: static tile assignment loses more than the hidden round trips gain.)
-template <bool GEN, bool ADD = false>
+template <bool GEN, bool ADD = false, bool POOL = false>
 __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
     extern __shared__ float4 sp_smem[];
     char *smem = reinterpret_cast<char *>(sp_smem);
@@ -256,6 +259,11 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
         rv[im] = P.rowvec ? P.rowvec[m] : 0.f;
         if (ADD) aoff[im] = (unsigned)(P.addend_rows ? P.addend_rows[m] : m) * (unsigned)(P.ldadd * 4) + (unsigned)kg * 16u;
     }
+    int gl = -1;                                            // POOL: graph of row m0 + 64 wm + lane (-1 past M)
+    if (POOL) {
+        const int m = m0 + wm * 64 + lane;
+        gl = m < P.M ? P.row_graph[m] : -1;
+    }
     float winv = *reinterpret_cast<const float *>(P.wp);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // K step 0 has landed (and the plain loads above)
     // the compiler does not see that wait: pin every loaded value here, or it places its own full wait at the
@@ -270,6 +278,7 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
 #pragma unroll
     for (int j = 0; j < SP_NPAR; ++j) asm volatile("" : "+v"(par[j]));
     asm volatile("" : "+v"(winv));
+    if (POOL) asm volatile("" : "+v"(gl));
     lds_barrier();
 
 #ifdef SP_STAMP
@@ -428,7 +437,7 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
     // staging tile of 32 rows x 128 columns (LDS operations of one wave complete in order: no barrier between its
     // writes and reads): row blocks 2 ib and 2 ib + 1 per pass.
     char *stg = smem + wid * SP_OWAVE;
-    if (P.y) {
+    if (P.y || POOL) {
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib) {
 #pragma unroll
@@ -440,16 +449,51 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
                         make_float4(v[0], v[1], v[2], v[3]);
                 }
             const int mb = m0 + wm * 64 + 32 * ib;
+            if (P.y) {
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int t = lane + 64 * it, row = t >> 5, c4 = t & 31;
-                const float4 v = *reinterpret_cast<const float4 *>(stg + row * SP_OSTRIDE + c4 * 16);
-                if (mb + row < P.M)
-                    *reinterpret_cast<float4 *>(P.y + (int64_t)(mb + row) * P.ldy + n0 + wn * 128 + c4 * 4) = v;
+                for (int it = 0; it < 16; ++it) {
+                    const int t = lane + 64 * it, row = t >> 5, c4 = t & 31;
+                    const float4 v = *reinterpret_cast<const float4 *>(stg + row * SP_OSTRIDE + c4 * 16);
+                    if (mb + row < P.M)
+                        *reinterpret_cast<float4 *>(P.y + (int64_t)(mb + row) * P.ldy + n0 + wn * 128 + c4 * 4) = v;
+                }
+            }
+            if constexpr (POOL) {
+                // readout of the staged 32 rows x 128 columns: a lane owns columns lane and lane + 64 and walks the rows
+                // (sorted by graph: a tile touches few graphs); one atomic per (graph, column) and pass.  Graph ids are
+                // wave-uniform (v_readlane), so the flush is a scalar branch.
+                float s0 = 0.f, s1 = 0.f;
+                int gcur = __builtin_amdgcn_readlane(gl, 32 * ib);
+                auto flush = [&](int g, float a, float b) {
+                    if (g < 0) return;
+                    const float w = P.pool_mean ? 1.f / (float)max(P.seg[g + 1] - P.seg[g], 1) : 1.f;
+                    float *dst = P.pool + (int64_t)g * P.ldp + n0 + wn * 128 + lane;
+                    unsafeAtomicAdd(dst, a * w);
+                    unsafeAtomicAdd(dst + 64, b * w);
+                };
+#pragma unroll
+                for (int r0 = 0; r0 < 32; r0 += 8) {
+                    // eight rows' values per batch of LDS reads (all 64 at once would not fit next to the accumulators)
+                    float v0[8], v1[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        v0[q] = *reinterpret_cast<const float *>(stg + (r0 + q) * SP_OSTRIDE + lane * 4);
+                        v1[q] = *reinterpret_cast<const float *>(stg + (r0 + q) * SP_OSTRIDE + (lane + 64) * 4);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int g = __builtin_amdgcn_readlane(gl, 32 * ib + r0 + q);
+                        if (g != gcur) { flush(gcur, s0, s1); s0 = s1 = 0.f; gcur = g; }
+                        s0 += v0[q]; s1 += v1[q];
+                    }
+                    asm volatile("" ::: "memory");
+                }
+                flush(gcur, s0, s1);
             }
         }
     }
-    if (P.ys) {
+    if (!POOL && P.ys) {                                     // (the readout variant writes fp32 rows or nothing: its
+        //                                                        accumulators retire pass by pass, the flush branches are cheap)
         // block scale = the row's largest magnitude over the tile's 256 columns (this wave + its column neighbour)
 #pragma unroll
         for (int im = 0; im < 4; ++im) {
@@ -500,21 +544,22 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
 #endif
 }
 
-template <bool GEN, bool ADD = false>
+template <bool GEN, bool ADD = false, bool POOL = false>
 static int launch_linear_sp_t(const LinearSpArgs &P, hipStream_t s) {
     static bool declared = false;
     if (!declared) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_sp<GEN, ADD>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_sp<GEN, ADD, POOL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS) != hipSuccess)
             return fail(BLGNN_ERR_LAUNCH, "linear_sp: cannot raise the dynamic LDS limit to %d bytes", SP_LDS);
         declared = true;
     }
     const int64_t blocks = (int64_t)((P.M + SP_BM - 1) / SP_BM) * (P.N / SP_BN);
-    hipLaunchKernelGGL((k_linear_sp<GEN, ADD>), dim3((unsigned)blocks), dim3(512), SP_LDS, s, P);
+    hipLaunchKernelGGL((k_linear_sp<GEN, ADD, POOL>), dim3((unsigned)blocks), dim3(512), SP_LDS, s, P);
     return launch_status("linear_sp");
 }
 
 static int launch_linear_sp(const LinearSpArgs &P, hipStream_t s) {
+    if (P.pool) return launch_linear_sp_t<false, false, true>(P, s);        // (relu / identity, no addend: checked by the caller)
     if (P.addend)
         return P.epi.act <= BLGNN_ACT_RELU ? launch_linear_sp_t<false, true>(P, s) : launch_linear_sp_t<true, true>(P, s);
     return P.epi.act <= BLGNN_ACT_RELU ? launch_linear_sp_t<false>(P, s) : launch_linear_sp_t<true>(P, s);
@@ -577,7 +622,8 @@ extern "C" int blgnn_linear_sp(const void *xs, int64_t ldxs, const uint8_t *xe, 
                                int32_t M, int32_t N, int32_t K, const float *bias, const float *rowvec,
                                const float *rowvec_w, int32_t act, const float *act_param,
                                const float *bn_scale, const float *bn_shift, const float *addend, int64_t ld_addend,
-                               const int32_t *addend_rows, int32_t num_addend_rows, void *stream) {
+                               const int32_t *addend_rows, int32_t num_addend_rows, const int32_t *row_graph,
+                               const int32_t *seg, float *pooled, int64_t ldp, int32_t pool_kind, void *stream) {
     BLGNN_CHECK_ARG(M >= 0 && N > 0 && K > 0, "linear_sp: bad sizes");
     if (M == 0) return BLGNN_OK;
     if (N % SP_BN != 0 || K % SP_BLOCK != 0 || K > 8 * SP_BLOCK)
@@ -589,7 +635,12 @@ extern "C" int blgnn_linear_sp(const void *xs, int64_t ldxs, const uint8_t *xe, 
     BLGNN_CHECK_ARG(!addend || (int64_t)num_addend_rows * ld_addend * 4 < ((int64_t)1 << 31),
                     "linear_sp: the addend must be smaller than 2 GiB (32-bit buffer offsets)");
     BLGNN_CHECK_ARG(addend || !addend_rows, "linear_sp: addend_rows without addend");
-    BLGNN_CHECK_ARG(xs && xe && w_packed && (y || ys), "linear_sp: null pointer");
+    BLGNN_CHECK_ARG(xs && xe && w_packed && (y || ys || pooled), "linear_sp: null pointer");
+    BLGNN_CHECK_ARG(!pooled || (row_graph && seg && ldp >= N && (pool_kind == BLGNN_REDUCE_SUM || pool_kind == BLGNN_REDUCE_MEAN)),
+                    "linear_sp: fused readout needs row_graph, seg, ldp >= N and a reduce kind");
+    if (pooled && (addend || ys || act > BLGNN_ACT_RELU))
+        return fail(BLGNN_ERR_UNSUPPORTED, "linear_sp: the fused readout goes with relu / identity, fp32 rows or no rows at "
+                    "all, and no addend");
     BLGNN_CHECK_ARG(ldxs >= 2 * (int64_t)K && ldxs % 8 == 0 && aligned16(xs) && ldxe >= K / SP_BLOCK,
                     "linear_sp: bad X planes (ldxs >= 2K, 16-byte aligned rows)");
     BLGNN_CHECK_ARG(ldxe % 8 == 0 && (reinterpret_cast<uintptr_t>(xe) & 7u) == 0,
@@ -609,5 +660,6 @@ extern "C" int blgnn_linear_sp(const void *xs, int64_t ldxs, const uint8_t *xe, 
     P.M = M; P.N = N; P.K = K; P.rowvec = rowvec; P.rowvec_w = rowvec_w;
     P.epi = Epilogue{bias, act_param, bn_scale, bn_shift, act};
     P.addend = addend; P.ldadd = ld_addend; P.addend_rows = addend_rows; P.n_addend = num_addend_rows;
+    P.row_graph = row_graph; P.seg = seg; P.pool = pooled; P.ldp = ldp; P.pool_mean = pool_kind == BLGNN_REDUCE_MEAN;
     return launch_linear_sp(P, (hipStream_t)stream);
 }

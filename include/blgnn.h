@@ -386,7 +386,12 @@ int blgnn_linear_h3(const float *x, int64_t ldx, const float *row_amax, const vo
  * addend (optional, fp32 rows of >= N columns, < 2 GiB): epi(X @ W + bias + rowvec (x) rowvec_w + addend[r(m), :]) with
  * r(m) = addend_rows[m] (int32 [M], rows of addend: num_addend_rows) or m -- the K-split of a GEMM whose leading
  * input columns repeat across rows: f_node's first Linear on [x | S | u] in the first propagator of a pair batch,
- * where [x | S] @ W[:3D] is computed once per distinct molecule (blgnn_expand_rows) and u @ W[3D:] for every atom. */
+ * where [x | S] @ W[:3D] is computed once per distinct molecule (blgnn_expand_rows) and u @ W[3D:] for every atom.
+ * pooled (optional, fp32 [G, >= N], zero-initialised by the caller): the node -> graph readout of the RESULT
+ * (model/layers_aggregation.py:16-19,32-41) in the epilogue, as in blgnn_gin_layer_h3 -- pooled[row_graph[m], :] +=
+ * result[m, :] (BLGNN_REDUCE_SUM) or / rows of that graph (BLGNN_REDUCE_MEAN); row_graph int32 [M] sorted, seg [G + 1].
+ * With pooled, y and ys may both be NULL (the rows themselves are then never written: the last propagator's hidden
+ * layer, whose second Linear commutes with the mean).  relu / identity only, no addend; fp32 atomics (low bits vary). */
 int64_t blgnn_packed_weight_sp_elems(int32_t K, int32_t N);
 int blgnn_pack_weight_sp(const float *w, int64_t ldw, int32_t K, int32_t N, void *out, void *stream);
 int blgnn_split_rows_sp(const float *x, int64_t ldx, int32_t M, int32_t K, void *xs, int64_t ldxs,
@@ -398,7 +403,8 @@ int blgnn_linear_sp(const void *xs, int64_t ldxs, const uint8_t *xe, int64_t ldx
                     int32_t M, int32_t N, int32_t K, const float *bias, const float *rowvec,
                     const float *rowvec_w, int32_t act, const float *act_param,
                     const float *bn_scale, const float *bn_shift, const float *addend, int64_t ld_addend,
-                    const int32_t *addend_rows, int32_t num_addend_rows, void *stream);
+                    const int32_t *addend_rows, int32_t num_addend_rows, const int32_t *row_graph,
+                    const int32_t *seg, float *pooled, int64_t ldp, int32_t pool_kind, void *stream);
 
 /* ---- GMN cross-graph attention ------------------------------------------ */
 

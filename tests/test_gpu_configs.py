@@ -44,8 +44,20 @@ def _gmn_model_vs_oracle(device, d, n_drugs, n_pairs, B, seed, dataset, edge_typ
     for layer in model.layers[:-1]:
         model.acts.append(layer(model.acts[-1], bd, model))
     assert len(model.acts) == len(acts)
+    pooled_seen = False
     for k, (got, ref) in enumerate(zip(model.acts[1:], acts[1:])):
+        kind = getattr(got, "_blgnn_pooled", None)
+        if kind is not None:
+            # the last propagator hands the readout its rows already pooled per graph (layers_gmn.py ``_readout_of``):
+            # compare with the oracle's node rows pooled the same way
+            b = bd.merge_data['merge'].batch.cpu()
+            G = int(b.max()) + 1
+            pooled = torch.zeros((G, ref.shape[1]), dtype=ref.dtype).index_add_(0, b, ref)
+            ref = pooled / torch.bincount(b, minlength=G).clamp(min=1).view(-1, 1).to(ref.dtype) if kind == "mean" else pooled
+            pooled_seen = True
         _check(got, ref, "layer %d (%s)" % (k, specs[k].split(":")[0]))
+    assert pooled_seen == bool(getattr(blgnn.config.FLAGS, "gmn_pooled_tail", True) and blgnn.layers_gmn.GMNPropagator._use_sp(
+        bd.merge_data['merge'].x.shape[0], d))
     return model.acts[-1]
 
 

@@ -108,6 +108,44 @@ def test_linear_sp_addend(device, M, K, N, act, mapped):
                       addend_rows=dv(rows)[:-1] if mapped else None)
 
 
+@pytest.mark.parametrize("M,K,N,act,kind,rows", [(1500, 512, 1024, "relu", "mean", False), (700, 256, 256, "identity", "sum", True),
+                                                 (257, 1024, 512, "relu", "mean", True)])
+def test_linear_sp_pooled_readout(device, M, K, N, act, kind, rows):
+    """the readout epilogue: pooled[g] = mean / sum over the rows of graph g of epi(X @ W + bias + rowvec (x) rowvec_w)
+    == fp64; graphs of 1..70 rows (several per 32-row staging pass, and graphs that span passes, waves and tiles), an
+    empty graph, ragged M; with the fp32 rows written as well, or not written at all"""
+    g = torch.Generator().manual_seed(M + K + N + 2)
+    sizes = []
+    while sum(sizes) < M:
+        sizes.append(int(torch.randint(1, 71, (1,), generator=g)))
+    sizes[-1] -= sum(sizes) - M
+    sizes.insert(3, 0)                                                # an empty graph: its pooled row stays 0
+    seg = torch.tensor([0] + sizes).cumsum(0).to(torch.int32)
+    G = len(sizes)
+    row_graph = torch.repeat_interleave(torch.arange(G), torch.tensor(sizes)).to(torch.int32)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(K, N, generator=g) / K ** 0.5
+    b, rv, rw = torch.randn(N, generator=g) * 0.1, torch.rand(M, generator=g) * 3, torch.randn(N, generator=g) * 0.1
+    D = lambda t: t.double()
+    full = oracle.apply_act(D(x) @ D(w) + D(b) + D(rv).view(-1, 1) * D(rw).view(1, -1), act, None)
+    ref = torch.zeros(G, N, dtype=torch.float64).index_add_(0, row_graph.long(), full)
+    if kind == "mean":
+        ref = ref / torch.tensor(sizes).clamp(min=1).view(-1, 1)
+    dv = lambda t: t.to(device)
+    pooled = torch.zeros(G, N + 4, device=device)
+    y, _ = ops.linear_sp(ops.split_rows_sp(dv(x)), dv(w), dv(b), act=act, rowvec=dv(rv), rowvec_w=dv(rw), f32=rows,
+                         pool=(dv(row_graph), dv(seg), pooled[:, :N], kind))
+    assert max_err(pooled[:, :N], ref) < TOL
+    assert float(pooled[:, N:].abs().max()) == 0.0 and float(pooled[3].abs().max()) == 0.0
+    if rows:
+        assert max_err(y, full) < TOL
+    else:
+        assert y is None
+    with pytest.raises(NotImplementedError):                          # no sp output next to the readout
+        ops.linear_sp(ops.split_rows_sp(dv(x)), dv(w), out_sp=ops.SpRows(M, N, device),
+                      pool=(dv(row_graph), dv(seg), pooled[:, :N], kind))
+
+
 @pytest.mark.parametrize("xs,ws", [(1e-6, 1.0), (3e4, 1.0), (1.0, 1e-5), (1.0, 300.0), (1e5, 1e-4), (1e-20, 1e10)])
 def test_linear_sp_range(device, xs, ws):
     """block scales inside one accumulator: tiny / huge activations and weights, rows and blocks of very different
@@ -262,3 +300,37 @@ def test_gmn_shared_prefix_equals_the_replicated_computation(device, d):
             # one chain over 4D columns (and at d=512 the unfused GIN layer's GEMMs pick their tile shape by the number
             # of rows): equal to fp32 rounding, not bit for bit
             assert max_err(u, v.cpu()) < 0.1 * TOL, "layer %d differs" % k
+
+
+def test_gmn_pooled_tail_equals_the_readout_of_node_rows(device):
+    """last propagator + multi-scale mean readout: hidden rows pooled in the GEMM epilogue and the second Linear applied per
+    graph (FLAGS.gmn_pooled_tail, default) == the readout of the node rows, to fp32 rounding; the layer's output is
+    then [G, D] tagged ``_blgnn_pooled``; pair scores agree"""
+    from helpers import build
+    from test_gpu_configs import _pairs
+    from blgnn.config import FLAGS
+    ds = blgnn.make_synthetic(90, 1200, shape="drugcombo", seed=8, device=device, num_edge_types=2)
+    flags = blgnn.make_flags("lower_level_gmn", dataset="drugcombo", lower_level_gnn_type="gin", D_lower=256,
+                             device=device, gmn_sp="force")
+    model, data = build(flags, ds, seed=9, num_hyper_edge_feat=3)
+    bd = blgnn.BatchData(_pairs(ds, 300), ds, is_train=False, unique_graphs=False)
+
+    def run(tail):
+        FLAGS.gmn_pooled_tail = tail
+        model.acts = [bd.merge_data['merge'].x]
+        for layer in model.layers[:-1]:
+            model.acts.append(layer(model.acts[-1], bd, model))
+        torch.cuda.synchronize()
+        return list(model.acts[1:])
+    a, b = run(True), run(False)
+    G, n = bd.merge_data['merge'].num_graphs, bd.merge_data['merge'].x.shape[0]
+    assert getattr(a[5], "_blgnn_pooled", None) == "mean" and tuple(a[5].shape) == (G, 256)
+    for k in (1, 3):                                                   # earlier propagators: node rows + their pooled rows
+        kind, pooled = a[k]._blgnn_pool_of
+        assert kind == "mean" and tuple(pooled.shape) == (G, 256) and tuple(a[k].shape) == (n, 256)
+        assert getattr(b[k], "_blgnn_pool_of", None) is None
+        assert max_err(a[k], b[k].cpu()) < 0.1 * TOL
+    assert getattr(b[5], "_blgnn_pooled", None) is None and tuple(b[5].shape) == (n, 256)
+    assert tuple(a[6].shape) == tuple(b[6].shape) == (G, 768)
+    assert max_err(a[6], b[6].cpu()) < 0.1 * TOL                       # the readout [G, 3 D]
+    assert max_err(a[-1], b[-1].cpu()) < 0.1 * TOL                     # pair scores
