@@ -173,6 +173,9 @@ __global__ void __launch_bounds__(512, 2) k_linear_sp(const LinearSpArgs P) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform by construction: keep it scalar
+#ifdef SP_STAMP
+    if (blockIdx.x == gridDim.x / 2 + 3 && tid == 0) { g_sp_stamps[6] = __builtin_amdgcn_s_memtime(); g_sp_stamps[7] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     const int nb = P.N / SP_BN;
     int tile;
     {   // blocks b, b + 8, ... share an XCD: give each XCD a contiguous run of tiles (row-panel major), so the
