@@ -473,7 +473,8 @@ int blgnn_scatter_rows(const float *src, int64_t lds, const int32_t *row_map,
  * (src/config.py:258) appends a molecule's tensors once per pair it occurs in, so every layer in front of the first
  * cross-graph attention computes identical rows ~(2 * pairs / distinct drugs) times; here those layers run on the
  * distinct molecules and their results (fp32 rows, sp piece planes, sp scale bytes) are replicated by this call.
- * 16-byte units when row_bytes, both leading dimensions and both pointers are multiples of 16, bytes otherwise. */
+ * 16-byte units when row_bytes, both leading dimensions and both pointers are multiples of 16, bytes otherwise.
+ * row_map values must lie in [0, rows of src): they are not checked on the device. */
 int blgnn_expand_rows(const void *src, int64_t ld_src, const int32_t *row_map, int64_t num_rows,
                       void *dst, int64_t ld_dst, int64_t row_bytes, void *stream);
 

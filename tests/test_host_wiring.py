@@ -65,6 +65,38 @@ def test_gmn_wiring(monkeypatch):
         assert max_err(got, ref) < 2e-5       # restructured message: summation order differs
 
 
+def test_gmn_readout_fusion_is_decided_from_the_layer_list():
+    """GMNPropagator._readout_of: the pooled-readout epilogues are taken only for a lower-level-only model driven layer by
+    layer over model.layers whose readout is a plain mean / sum; the last propagator alone may drop its node rows"""
+    from blgnn.config import FLAGS
+    ds = blgnn.make_synthetic(12, 30, shape="drugcombo", seed=3, device="cpu", num_edge_types=2)
+    flags = blgnn.make_flags("lower_level_gmn", dataset="drugcombo", lower_level_gnn_type="gin", D_lower=64, device="cpu")
+    model, _ = build(flags, ds, seed=4, num_hyper_edge_feat=3)
+    layers = list(model.layers)
+    props = [k for k, l in enumerate(layers) if type(l).__name__ == "GMNPropagator"]
+    assert len(props) == 3
+    for k in props:
+        model.acts = [None] * (k + 1)                              # the forward loop is about to call layer k
+        assert layers[k]._readout_of(model) == ("mean", k == props[-1])
+        model.acts = [None] * (k + 2)                              # called out of turn: not the model's own forward
+        assert layers[k]._readout_of(model) == (None, False)
+    model.acts = [None] * (props[-1] + 1)
+    FLAGS.gmn_pooled_tail = False
+    assert layers[props[-1]]._readout_of(model) == (None, False)
+    FLAGS.gmn_pooled_tail = True
+    agg = layers[props[-1] + 1]
+    keep = agg.concat_multi_scale
+    agg.concat_multi_scale = False                                 # readout of the last layer only: earlier rows are not pooled
+    model.acts = [None] * (props[0] + 1)
+    assert layers[props[0]]._readout_of(model) == (None, False)
+    model.acts = [None] * (props[-1] + 1)
+    assert layers[props[-1]]._readout_of(model) == ("mean", True)
+    agg.concat_multi_scale = keep
+    FLAGS.higher_level_layers = True                               # a bi-level model reads init_x rows: node rows stay
+    assert layers[props[-1]]._readout_of(model) == (None, False)
+    FLAGS.higher_level_layers = False
+
+
 def test_drugcombo_meta_wiring(monkeypatch):
     fake_backend.install(monkeypatch)
     ds = blgnn.make_synthetic(25, 100, seed=3, device="cpu", num_edge_types=2)
