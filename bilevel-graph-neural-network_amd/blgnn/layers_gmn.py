@@ -300,9 +300,14 @@ class GMNPropagator(nn.Module):
                 pooled_hid = torch.zeros((G, 4 * D), dtype=torch.float32, device=x.device)
                 ops.linear_sp(f_sp, w1, b1, act=act, rowvec=ops.row_degree(csr), rowvec_w=rw,
                               pool=(merge.row_graph(), seg, pooled_hid, tail), f32=False)
-                sizes = (seg[1:] - seg[:-1]).to(torch.float32)              # (index arithmetic on the segment table)
-                scale = sizes if tail == "sum" else (sizes > 0).to(torch.float32)
-                out = ops.linear(pooled_hid, self.f_node.weight_kn(1), None, rowvec=scale.contiguous(),
+                scale = getattr(merge, "_bias_rows", {}).get(tail)           # per batch, like the segment table itself
+                if scale is None:
+                    sizes = (seg[1:] - seg[:-1]).to(torch.float32)          # (index arithmetic on the segment table)
+                    scale = (sizes if tail == "sum" else (sizes > 0).to(torch.float32)).contiguous()
+                    if not hasattr(merge, "_bias_rows"):
+                        merge._bias_rows = {}
+                    merge._bias_rows[tail] = scale
+                out = ops.linear(pooled_hid, self.f_node.weight_kn(1), None, rowvec=scale,
                                  rowvec_w=self.f_node.layers[1].bias)
                 out._blgnn_pooled = tail                                    # [G, D]: the readout takes it as is
                 model.store_layer_output(self, out)
