@@ -262,10 +262,11 @@ class GMNPropagator(nn.Module):
             # Where the attention forks off (FLAGS.gmn_match_fork): "message" (default) = beside the message GEMM AND the
             # edge kernel, "edge" = beside the edge kernel only.  The attention's workgroups (66-133 KB of LDS) and the
             # GEMM's (141 KB) exclude each other on a CU, so beside the GEMM the two add up (the K = 256 GEMM stretches from
-            # 1.0 to 1.85 ms in the step's kernel trace); the edge kernel is HBM-bound and uses no LDS, but its 0.6 ms do
-            # not cover the attention's 1.2-1.7 ms chain.  Measured A/B in one process (ms per step, configs[2]):
-            # message 20.04 / 19.95, edge 20.82 / 20.74; with two attention streams 20.07 / 20.07 and 20.60 / 20.40; the
-            # common size class beside the GEMM and the two rarer ones beside the edge kernel: 20.47 vs 19.83.
+            # 1.0 to 1.7 ms in the step's kernel trace); the edge kernel is HBM-bound and uses no LDS, but its 0.6 ms do
+            # not cover the attention's 1.3 ms chain.  Measured A/B in one process on the plain path (ms per step,
+            # configs[2]): message 20.04 / 19.95, edge 20.82 / 20.74; with two attention streams 20.07 / 20.07 and
+            # 20.60 / 20.40; the common size class beside the GEMM and the two rarer ones beside the edge kernel: 20.47 vs
+            # 19.83.
             fork = getattr(FLAGS, "gmn_match_fork", "message") if side is not None else None
             if fork == "message":
                 fork_match()
