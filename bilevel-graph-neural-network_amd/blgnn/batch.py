@@ -48,6 +48,34 @@ class _Pair(object):
         return float(p[0]) if p.shape[0] == 1 else p
 
 
+class _PairList(object):
+    """``pair_list`` of the reference (src/batch.py:112-114: one GraphPair per row of the batch) as a sequence of lazy
+    views: a 4 096-pair training batch does not build 4 096 python objects nobody reads."""
+
+    __slots__ = ("_batch", "_n")
+
+    def __init__(self, batch, n):
+        self._batch, self._n = batch, int(n)
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [_Pair(self._batch, k) for k in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        return _Pair(self._batch, i)
+
+    def __iter__(self):
+        return (_Pair(self._batch, k) for k in range(self._n))
+
+    def __eq__(self, other):
+        return list(self) == other if isinstance(other, list) else NotImplemented
+
+
 class SharedMolecules(object):
     """``graph``: GraphData of the distinct molecules of a pair batch; ``row_map`` int32 [n] (device): merged atom ->
     its row in ``graph``."""
@@ -83,11 +111,16 @@ class BatchData(object):
             self.sample_negative_pairs(enforce_negative_sampling,
                                        rng if rng is not None else np.random.default_rng())
         self.merge_data, self.pair_list = self._merge_into_one_graph(self.batch_gids)
-        gs_map = self.dataset.gs_map
-        self.batch_interaction_inds = [gs_map[g] for g in self.batch_gids.flatten()]
+        self.batch_interaction_inds = self._rows_of(self.batch_gids.reshape(-1)).tolist()
         self.merge_higher_level = {}
         if subgraph is not None:
             raise NotImplementedError("sampled subgraphs (use_sampled_subgraph) are outside the hot path")
+
+    def _rows_of(self, gids):
+        """gs_map[gid] of an int array (dense table of the dataset when it has one)."""
+        if hasattr(self.dataset, "rows_of_gids"):
+            return self.dataset.rows_of_gids(gids)
+        return np.vectorize(self.dataset.gs_map.__getitem__, otypes=[np.int64])(np.asarray(gids, dtype=np.int64))
 
     # -- negatives: src/batch.py:61-103 ------------------------------------------------
     def sample_negative_pairs(self, enforce_negative, rng):
@@ -100,10 +133,13 @@ class BatchData(object):
             want = int(min(want, n * (n - 1) // 2 - len(self.batch_gids)))
         pos = self.dataset.positive_pair_keys()
         N = np.int64(self.dataset.num_graphs())
-        rows = np.vectorize(gs_map.get)
+        rows = self._rows_of
         bp = rows(self.positive_pair_gids)
         pos = np.union1d(pos, np.minimum(bp[:, 0], bp[:, 1]) * N + np.maximum(bp[:, 0], bp[:, 1]))
-        chosen, seen = [], set()
+        # rounds of candidates, accepted in candidate order: not a self pair, not a known positive, not drawn before
+        # (the acceptance rules of src/batch.py:75-98, on whole arrays instead of one candidate per python iteration)
+        chosen = np.zeros((0, 2), dtype=np.int64)
+        seen = np.zeros(0, dtype=np.int64)
         cursor = 0
         while len(chosen) < want:
             m = max(2 * (want - len(chosen)), 16)
@@ -113,18 +149,21 @@ class BatchData(object):
             if enforce_negative:
                 ra, rb = rows(a), rows(b)
                 key = np.minimum(ra, rb) * N + np.maximum(ra, rb)
-                ok = (a != b) & ~np.isin(key, pos)
+                ok = (a != b) & ~np.isin(key, pos) & ~np.isin(key, seen)
+                first = np.zeros(m, dtype=bool)
+                first[np.unique(key, return_index=True)[1]] = True          # first occurrence of a key in this round
+                ok &= first
+                # (a key's first occurrence may itself be rejected only for being a self pair / positive / seen, and then
+                #  every later occurrence of that key is rejected for the same reason)
             else:
                 key = np.arange(m)
                 ok = np.ones(m, dtype=bool)
-            for x, y, k, good in zip(a, b, key, ok):
-                if good and (not enforce_negative or int(k) not in seen):
-                    seen.add(int(k))
-                    chosen.append((int(x), int(y)))
-                    if len(chosen) == want:
-                        break
-        if chosen:
-            self.negative_pair_gids = np.asarray(chosen)
+            take = np.flatnonzero(ok)[:want - len(chosen)]
+            chosen = np.concatenate((chosen, np.stack((a[take], b[take]), axis=1).astype(np.int64)))
+            if enforce_negative:
+                seen = np.concatenate((seen, key[take]))
+        if len(chosen):
+            self.negative_pair_gids = chosen
             self._neg_start = len(self.batch_gids)
             self.batch_gids = np.concatenate((self.batch_gids, self.negative_pair_gids))
 
@@ -142,9 +181,7 @@ class BatchData(object):
         labels = self.dataset.labels_of(self.positive_pair_gids)
         n_neg = len(batch_gids) - len(self.positive_pair_gids)
         self._labels = np.concatenate([labels, np.zeros(n_neg, dtype=np.int64)])
-        pair_list = [_Pair(self, i) for i in range(len(batch_gids))]
-        assert len(pair_list) == batch_gids.shape[0]
-        return merged, pair_list
+        return merged, _PairList(self, len(batch_gids))
 
     def shared_molecules(self):
         """Pair batches (``unique_graphs=False``: src/config.py:258 for the GMN model) hold one copy of a molecule per
@@ -174,8 +211,7 @@ class BatchData(object):
         """gs_map[gid] for every graph of the merged batch, int32 on the device."""
         rows = getattr(self, "_graph_rows", None)
         if rows is None:
-            gs_map = self.dataset.gs_map
-            host = np.asarray([gs_map[g] for g in self._graph_gids], dtype=np.int32)
+            host = self._rows_of(np.asarray(self._graph_gids, dtype=np.int64)).astype(np.int32)
             rows = torch.as_tensor(host).to(self.merge_data['merge'].x.device)
             self._graph_rows = rows
             # contiguous ascending run of rows (a sweep over the drugs in gs_map order): the readout can

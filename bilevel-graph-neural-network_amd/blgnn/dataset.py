@@ -52,7 +52,30 @@ class BiGNNDataset(object):
         gids = np.asarray(gids, dtype=np.int64)
         if gids.size == 0:
             return gids.reshape(-1, 2)
-        return np.vectorize(self.gs_map.get, otypes=[np.int64])(gids)
+        return self.rows_of_gids(gids)
+
+    def rows_of_gids(self, gids):
+        """gs_map[gid] for an int array of any shape through a dense table (built once; graph ids are small
+        non-negative integers in every dataset of this path, else the dict is walked); unknown ids raise KeyError
+        as the dict lookup of the reference does."""
+        gids = np.asarray(gids, dtype=np.int64)
+        lut = getattr(self, "_gid_lut", None)
+        if lut is None or getattr(self, "_gid_lut_len", -1) != len(self.gs_map):
+            keys = np.fromiter(self.gs_map.keys(), dtype=np.int64, count=len(self.gs_map))
+            if len(keys) and keys.min() >= 0 and keys.max() < 16 * len(keys) + 1024:
+                lut = np.full(int(keys.max()) + 1, -1, dtype=np.int64)
+                lut[keys] = np.fromiter(self.gs_map.values(), dtype=np.int64, count=len(self.gs_map))
+            else:
+                lut = False
+            self._gid_lut, self._gid_lut_len = lut, len(self.gs_map)
+        if lut is False:
+            return np.vectorize(self.gs_map.__getitem__, otypes=[np.int64])(gids)
+        if gids.size and (gids.min() < 0 or gids.max() >= lut.shape[0]):
+            raise KeyError(int(gids.max() if gids.max() >= lut.shape[0] else gids.min()))
+        rows = lut[gids]
+        if (rows < 0).any():
+            raise KeyError(int(gids[rows < 0].reshape(-1)[0]))
+        return rows
 
     def num_graphs(self):
         return len(self.molecules)

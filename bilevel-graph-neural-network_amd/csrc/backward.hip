@@ -17,7 +17,13 @@
 
 namespace blgnn {
 
-constexpr int CR_ROWS = 512;            // rows per partial-reduction chunk
+constexpr int CR_ROWS = 512;            // most rows per partial-reduction chunk
+// rows per chunk: enough chunks to fill the chip on the matrices of this path (37 k x 128 -> 290 chunks of 128 rows;
+// with 512 rows the 146 workgroups each ran 128 dependent strided loads: 29 us for 19 MB)
+static inline int cr_rows(int M) {
+    int r = ((M + 511) / 512 + 31) / 32 * 32;
+    return r < 64 ? 64 : (r > CR_ROWS ? CR_ROWS : r);
+}
 enum { COL_SUM = 0, COL_DOT = 1, COL_SQDEV = 2, COL_DOT_NORM = 3 };
 
 // partial[chunk][c] = sum over the chunk's rows of  a  |  a * b  |  (a - mean[c])^2  |  a * (b - mean[c]) * rstd[c]
@@ -25,13 +31,13 @@ template <int MODE>
 __global__ void __launch_bounds__(256) k_col_partial(const float *__restrict__ a, int64_t lda,
                                                      const float *__restrict__ b, int64_t ldb,
                                                      const float *__restrict__ mean,
-                                                     const float *__restrict__ rstd, int M, int N,
+                                                     const float *__restrict__ rstd, int M, int N, int rows,
                                                      float *__restrict__ partial) {
-    // 64 columns x 4 row lanes per workgroup pass; grid = (column strips of 64, row chunks)
+    // 64 columns x 4 row lanes per workgroup pass; grid = (column strips of 64, row chunks of ``rows``)
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;                                  // 0..3
-    const int r0 = blockIdx.y * CR_ROWS;
-    const int r1 = min(r0 + CR_ROWS, M);
+    const int r0 = blockIdx.y * rows;
+    const int r1 = min(r0 + rows, M);
     float s = 0.f;
     if (c < N) {
         const float mu = (MODE == COL_SQDEV || MODE == COL_DOT_NORM) ? mean[c] : 0.f;
@@ -52,12 +58,27 @@ __global__ void __launch_bounds__(256) k_col_partial(const float *__restrict__ a
                                                (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-__global__ void k_col_final(const float *__restrict__ partial, int chunks, int N, float scale, float *__restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+// out[c] = scale * sum over the chunks' partials, in a FIXED order: four row lanes take chunks k = lane, lane + 4, ...
+// (four loads in flight each), their sums are combined as (s0 + s1) + (s2 + s3).  64 columns per workgroup.
+__global__ void __launch_bounds__(256) k_col_final(const float *__restrict__ partial, int chunks, int N, float scale,
+                                                   float *__restrict__ out) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
     float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += partial[(int64_t)k * N + c];     // fixed order
-    out[c] = s * scale;
+    if (c < N) {
+        int k = rl;
+        for (; k + 12 < chunks; k += 16) {
+            const float v0 = partial[(int64_t)k * N + c], v1 = partial[(int64_t)(k + 4) * N + c];
+            const float v2 = partial[(int64_t)(k + 8) * N + c], v3 = partial[(int64_t)(k + 12) * N + c];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; k < chunks; k += 4) s += partial[(int64_t)k * N + c];
+    }
+    __shared__ float red[4][64];
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < N)
+        out[c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) * scale;
 }
 
 // y = (x - mean) * rstd * gamma + beta
@@ -174,16 +195,25 @@ __global__ void k_pair_scatter_add(const float *__restrict__ dcat, int64_t ldc, 
 // partial product with exact-f32 MFMA straight from the row-major operands (lane fi reads g[row, 32 to + fi] as the A
 // fragment and x[row, 32 ti + fi] as the B fragment: both coalesced, no transpose, no LDS), partials go to scratch and
 // k_col_final adds them in a fixed order (deterministic).  The forward GEMM kernels are shaped for the opposite case.
-constexpr int GW_ROWS = 1024;
+constexpr int GW_ROWS = 1024;           // most rows per chunk
+// rows per chunk: at least ~one workgroup per CU (37 k x 128 x 128: 290 chunks of 128 rows instead of 37 of 1 024, whose
+// 64 dependent operand round trips each made the launch 306 us)
+static inline int gw_rows(int M, int O, int I) {
+    const int tiles = ((O + 127) / 128) * ((I + 127) / 128);
+    const int want = (512 + tiles - 1) / tiles;                        // chunks wanted
+    int r = ((M + want - 1) / want + 15) / 16 * 16;
+    return r < 128 ? 128 : (r > GW_ROWS ? GW_ROWS : r);
+}
 typedef float f32x16g __attribute__((ext_vector_type(16)));
 
 __global__ void __launch_bounds__(256) k_grad_weight(const float *__restrict__ g, int64_t ldg, const float *__restrict__ x,
-                                                     int64_t ldx, int M, int O, int I, float *__restrict__ partial) {
+                                                     int64_t ldx, int M, int O, int I, int rows,
+                                                     float *__restrict__ partial) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int fi = lane & 31, fh = lane >> 5;
     const int bi_n = (I + 127) / 128;
     const int o0 = (blockIdx.y / bi_n) * 128 + (wid >> 1) * 64, i0 = (blockIdx.y % bi_n) * 128 + (wid & 1) * 64;
-    const int r0 = blockIdx.x * GW_ROWS, r1 = min(r0 + GW_ROWS, M);
+    const int r0 = blockIdx.x * rows, r1 = min(r0 + rows, M);
     f32x16g acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -234,7 +264,8 @@ static unsigned grid_for(int64_t items, int threads) { return (unsigned)((items 
 using namespace blgnn;
 
 extern "C" int64_t blgnn_col_reduce_scratch_elems(int32_t M, int32_t N) {
-    return (int64_t)((M + CR_ROWS - 1) / CR_ROWS) * N;
+    const int rows = cr_rows(M);
+    return (int64_t)((M + rows - 1) / rows) * N;
 }
 
 extern "C" int blgnn_col_reduce(const float *a, int64_t lda, const float *b, int64_t ldb, const float *mean,
@@ -246,20 +277,22 @@ extern "C" int blgnn_col_reduce(const float *a, int64_t lda, const float *b, int
     BLGNN_CHECK_ARG((mode != COL_SQDEV && mode != COL_DOT_NORM) || mean, "col_reduce: this mode needs the column means");
     BLGNN_CHECK_ARG(mode != COL_DOT_NORM || rstd, "col_reduce: dot_norm mode needs rstd");
     hipStream_t s = (hipStream_t)stream;
-    const int chunks = (M + CR_ROWS - 1) / CR_ROWS;
+    const int rows = cr_rows(M);
+    const int chunks = (M + rows - 1) / rows;
     if (chunks > 0) {
         dim3 grid((N + 63) / 64, chunks);
-        if (mode == COL_SUM) hipLaunchKernelGGL(k_col_partial<COL_SUM>, grid, dim3(256), 0, s, a, lda, b, ldb, mean, rstd, M, N, scratch);
-        else if (mode == COL_DOT) hipLaunchKernelGGL(k_col_partial<COL_DOT>, grid, dim3(256), 0, s, a, lda, b, ldb, mean, rstd, M, N, scratch);
-        else if (mode == COL_SQDEV) hipLaunchKernelGGL(k_col_partial<COL_SQDEV>, grid, dim3(256), 0, s, a, lda, b, ldb, mean, rstd, M, N, scratch);
-        else hipLaunchKernelGGL(k_col_partial<COL_DOT_NORM>, grid, dim3(256), 0, s, a, lda, b, ldb, mean, rstd, M, N, scratch);
+        if (mode == COL_SUM) hipLaunchKernelGGL(k_col_partial<COL_SUM>, grid, dim3(256), 0, s, a, lda, b, ldb, mean, rstd, M, N, rows, scratch);
+        else if (mode == COL_DOT) hipLaunchKernelGGL(k_col_partial<COL_DOT>, grid, dim3(256), 0, s, a, lda, b, ldb, mean, rstd, M, N, rows, scratch);
+        else if (mode == COL_SQDEV) hipLaunchKernelGGL(k_col_partial<COL_SQDEV>, grid, dim3(256), 0, s, a, lda, b, ldb, mean, rstd, M, N, rows, scratch);
+        else hipLaunchKernelGGL(k_col_partial<COL_DOT_NORM>, grid, dim3(256), 0, s, a, lda, b, ldb, mean, rstd, M, N, rows, scratch);
     }
-    hipLaunchKernelGGL(k_col_final, dim3((N + 255) / 256), dim3(256), 0, s, scratch, chunks, N, scale, out);
+    hipLaunchKernelGGL(k_col_final, dim3((N + 63) / 64), dim3(256), 0, s, scratch, chunks, N, scale, out);
     return launch_status("col_reduce");
 }
 
 extern "C" int64_t blgnn_grad_weight_scratch_elems(int32_t M, int32_t O, int32_t I) {
-    return (int64_t)((M + GW_ROWS - 1) / GW_ROWS) * O * I;
+    const int rows = gw_rows(M, O, I);
+    return (int64_t)((M + rows - 1) / rows) * O * I;
 }
 
 extern "C" int blgnn_grad_weight(const float *g, int64_t ldg, const float *x, int64_t ldx, int32_t M, int32_t O, int32_t I,
@@ -267,11 +300,12 @@ extern "C" int blgnn_grad_weight(const float *g, int64_t ldg, const float *x, in
     BLGNN_CHECK_ARG(M >= 0 && O > 0 && I > 0 && ldg >= O && ldx >= I, "grad_weight: bad sizes");
     BLGNN_CHECK_ARG((M == 0 || (g && x)) && scratch && dw, "grad_weight: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    const int chunks = (M + GW_ROWS - 1) / GW_ROWS;
+    const int rows = gw_rows(M, O, I);
+    const int chunks = (M + rows - 1) / rows;
     if (chunks > 0)
         hipLaunchKernelGGL(k_grad_weight, dim3(chunks, ((O + 127) / 128) * ((I + 127) / 128)), dim3(256), 0, s, g, ldg, x, ldx,
-                           M, O, I, scratch);
-    hipLaunchKernelGGL(k_col_final, dim3((O * I + 255) / 256), dim3(256), 0, s, scratch, chunks, O * I, 1.f, dw);
+                           M, O, I, rows, scratch);
+    hipLaunchKernelGGL(k_col_final, dim3((O * I + 63) / 64), dim3(256), 0, s, scratch, chunks, O * I, 1.f, dw);
     return launch_status("grad_weight");
 }
 
