@@ -111,6 +111,8 @@ def parse():
     ap.add_argument("--no-pooled-tail", action="store_true",
                     help="GMN configs: write every propagator's node rows and run the readout as its own launch instead of "
                          "pooling in the GEMM epilogues (and the last second Linear per graph)")
+    ap.add_argument("--train-eager", action="store_true",
+                    help="--train: run the iteration launch by launch instead of replaying its HIP graph")
     ap.add_argument("--no-gmn-sp", action="store_true",
                     help="GMN configs: the in-kernel operand split of blgnn_linear_h3 instead of the pre-split pipeline")
     ap.add_argument("--gmn-match-fork", choices=("message", "edge"), default=None,
@@ -881,18 +883,22 @@ def run_train(args, D, transform, steps, warmup):
     rng = np.random.default_rng(SEED)
     lower_cache = []
     losses = []
+    captured = not getattr(args, "train_eager", False)
+
+    def next_batch():
+        # the host side of an iteration: draw positives, sample one negative per positive (src/batch.py:61-103)
+        while True:
+            pos = ds.pair_gids[rng.choice(len(ds.pair_gids), size=batch, replace=False)]
+            bd = BatchData(pos, ds, sampled_gids=np.unique(pos), is_train=True, rng=rng)
+            if len(bd.batch_gids) == 2 * batch:
+                return bd
+    # blgnn.TrainStep: the iteration (sweep with gradients -> init_x -> pair batch -> loss -> backward -> SGD) captured in
+    # a HIP graph and replayed per batch; --train-eager runs the identical iteration launch by launch
+    ts = blgnn.TrainStep(model, data, opt, next_batch(), lower_cache=lower_cache, capture=captured)
 
     def step(_i):
-        pos = ds.pair_gids[rng.choice(len(ds.pair_gids), size=batch, replace=False)]
-        opt.zero_grad(set_to_none=True)
-        get_initial_embd(data, model, cached_batches=lower_cache)          # sweep WITH gradients -> init_x
-        ds.init_interaction_graph_embds(device)
-        bd = BatchData(pos, ds, sampled_gids=np.unique(pos), is_train=True, rng=rng)
-        model.use_layers = 'higher_layers'
-        loss = model(bd)
-        loss.backward()
-        opt.step()
-        losses.append(loss.detach())
+        bd = next_batch()
+        losses.append(ts.step(bd).clone())
         return len(bd.batch_gids)
     for i in range(warmup):
         step(i)
@@ -912,6 +918,8 @@ def run_train(args, D, transform, steps, warmup):
                                   "drugs with gradients + %d positive and as many sampled negative pairs per step"
                                   % (cfg["drugs"], batch),
                       "atoms": int(lower_cache[0].merge_data['merge'].x.shape[0]), "optimizer": "SGD(momentum 0.9)",
+                      "iteration": "captured in one HIP graph, replayed per batch (blgnn.TrainStep)" if captured
+                                   else "eager (--train-eager)",
                       "loss_first3_mean": first, "loss_last3_mean": last}}
     if not args.no_cpu_baseline:
         # the oracle with torch autograd on the host cores: same model, same sizes, bounded number of steps

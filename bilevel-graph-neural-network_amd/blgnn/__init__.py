@@ -24,5 +24,6 @@ from .layers_link_pred import LinkPred                                  # noqa: 
 from .layers_factory import create_layers, layer_ctors                  # noqa: E402
 from .model import Model                                                # noqa: E402
 from .engine import BiLevelEngine                                       # noqa: E402
+from .train_step import TrainStep                                       # noqa: E402
 
 __version__ = "0.1.0"

@@ -305,7 +305,8 @@ class NodeEmbedding(nn.Module):
         act = act_name(self.act)
         if self.type == 'gin':
             lin1, lin2 = self.conv.nn[0], self.conv.nn[2]
-            agg = ag.spmm_sum(ins, csr, 1.0 + float(self.conv.eps[0]))
+            # (eps is a buffer, not trained: read once per version, no device -> host copy per step)
+            agg = ag.spmm_sum(ins, csr, 1.0 + self._cache.get("eps", lambda e: float(e[0]), self.conv.eps))
             h = ag.linear(agg, lin1.weight, lin1.bias, act)
             x = ag.linear(h, lin2.weight, lin2.bias, act)           # conv, then the layer's act (layers.py:55)
         elif self.type == 'gat':

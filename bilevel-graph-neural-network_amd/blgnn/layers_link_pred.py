@@ -53,9 +53,12 @@ class LinkPred(nn.Module):
         if isinstance(batch_gids, torch.Tensor):
             batch_gids = batch_gids.cpu().numpy()
         if self.batch_unique_graphs:
-            table = batch_data.dataset.gs_map if FLAGS.higher_level_layers \
-                else batch_data.merge_data['gids_to_batch_ind']
-            ids = np.vectorize(table.get)(batch_gids)
+            if FLAGS.higher_level_layers and hasattr(batch_data.dataset, "rows_of_gids"):
+                ids = batch_data.dataset.rows_of_gids(batch_gids)            # gs_map through its dense table
+            else:
+                table = batch_data.dataset.gs_map if FLAGS.higher_level_layers \
+                    else batch_data.merge_data['gids_to_batch_ind']
+                ids = np.vectorize(table.get)(batch_gids)
         else:
             ids = np.arange(batch_gids.shape[0] * batch_gids.shape[1]).reshape(batch_gids.shape)
         return np.ascontiguousarray(ids, dtype=np.int64)
