@@ -108,6 +108,8 @@ def parse():
                     help="GMN configs: compute every copy of a molecule in the pair batch (the reference's batch as is) "
                          "instead of running the layers in front of the first cross-graph attention on the distinct "
                          "molecules")
+    ap.add_argument("--no-gin-sp", action="store_true",
+                    help="wide GIN layers as one fused launch instead of aggregation + two pre-split GEMMs")
     ap.add_argument("--no-pooled-tail", action="store_true",
                     help="GMN configs: write every propagator's node rows and run the readout as its own launch instead of "
                          "pooling in the GEMM epilogues (and the last second Linear per graph)")
@@ -384,6 +386,7 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
                              higher_level_gnn_type="gat", D_lower=d, D_higher=d, device=device,
                              batch_size=batch, feature_transform=transform,
                              fuse_readout=not args.no_fuse_readout)
+    flags.gin_sp = not getattr(args, "no_gin_sp", False)
     blgnn.set_flags(flags)
     torch.manual_seed(seed)
     data = blgnn.TrainData(ds, device=device)
@@ -596,6 +599,7 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
     flags.gmn_sp = not getattr(args, "no_gmn_sp", False)
     flags.gmn_shared_prefix = not getattr(args, "no_shared_prefix", False)
     flags.gmn_pooled_tail = not getattr(args, "no_pooled_tail", False)
+    flags.gin_sp = not getattr(args, "no_gin_sp", False)
     flags.gmn_match_streams = int(getattr(args, "gmn_match_streams", 1))
     if getattr(args, "gmn_match_fork", None):
         flags.gmn_match_fork = args.gmn_match_fork

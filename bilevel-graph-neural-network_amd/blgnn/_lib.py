@@ -32,6 +32,7 @@ SIGNATURES = {
     "blgnn_csr_from_coo": [_p, _p, _i64, _i32, _p, _p, _p, _p],
     "blgnn_segments_from_batch": [_p, _i64, _i32, _p, _p],
     "blgnn_spmm_sum": [_p, _p, _i64, _p, _p, _i64, _p, _i64, _i32, _i32, _f32, _i32, _p],
+    "blgnn_spmm_sum_sp": [_p, _p, _i64, _p, _i64, _i32, _i32, _f32, _i32, _p, _i64, _p, _i64, _p],
     "blgnn_gin_layer": [_p, _p, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _p, _i32, _f32, _i32, _p, _p, _p,
                         _p, _i64, _p],
     "blgnn_pack_weight_x6": [_p, _i64, _i32, _i32, _p, _p],

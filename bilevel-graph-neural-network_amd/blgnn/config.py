@@ -163,6 +163,8 @@ def make_flags(model="higher_level_gnn", dataset="drugbank", lower_level_gnn_typ
     f.gmn_match_streams = 1                            # side streams of the attention's size-class kernels (1 | 2)
     f.gmn_shared_prefix = True                         # pair batches: the layers in front of the first cross-graph
     #                                                    attention run on the distinct molecules (layers.py)
+    f.gin_sp = True                                    # GIN layers at d >= 512 on large batches: aggregation into the sp format +
+    #                                                    two pre-split GEMMs (layers.py; ops.gin_sp_preferred)
     f.gmn_pooled_tail = True                           # last propagator + mean / sum readout: pool the hidden rows in the
     #                                                    GEMM epilogue, second Linear per graph (layers_gmn.py)
     if last_lower is not None:

@@ -230,6 +230,25 @@ class NodeEmbedding(nn.Module):
                                                self.out_dim, eps=eps, act=act, act_param=slopes, bn_scale=scale,
                                                bn_shift=shift, out=out, pool=pool)
                     fused_pool = True
+                elif transform == "f16x3" and out is None and wide is None and getattr(FLAGS, "gin_sp", True) and \
+                        ops.gin_sp_preferred(csr, ins, self.out_dim, force=getattr(FLAGS, "gin_sp", True) == "force"):
+                    # layers wider than the single-launch f16x3 kernel covers (d = 512), on large batches: aggregation
+                    # straight into the sp format + the two Linears as pre-split GEMMs; the readout rides on the second
+                    # GEMM's epilogue, and so do the sp planes a GMN propagator reads
+                    n_rows, N = ins.shape[0], self.out_dim
+                    agg_sp = ops.spmm_sum_sp(csr, ins, self_coef=1.0 + eps, skip_self=True)
+                    h_sp = ops.SpRows(n_rows, N, ins.device)
+                    ops.linear_sp(agg_sp, w1, lin1.bias, act=act, act_param=slopes, out_sp=h_sp)
+                    f_sp = ops.SpRows(n_rows, 4 * N, ins.device) if want_sp else None      # (any whole-block width)
+                    sp_x = f_sp.cols(0, N) if f_sp is not None else None
+                    pool_here = pool if (pool is not None and sp_x is None and act in ("relu", "identity")) else None
+                    x, _ = ops.linear_sp(h_sp, w2, lin2.bias, act=act, act_param=slopes, bn_scale=scale, bn_shift=shift,
+                                         out_sp=sp_x, f32=True, pool=pool_here)
+                    if sp_x is not None and shared is None:
+                        x._blgnn_sp = f_sp
+                    if shared is not None:
+                        shared_sp = f_sp
+                    fused_pool = pool_here is not None
                 elif transform == "f16x3" and ops.gin_layer_h3_supported(csr, ins, ins.shape[1], self.out_dim):
                     # dense transforms on the fp16 matrix cores at fp32 accuracy (scaled two-piece split)
                     w1p = self._cache.get("w1h", lambda w: ops.pack_weight_h3(w.t().contiguous()), lin1.weight)

@@ -143,6 +143,31 @@ def spmm_sum(csr, x, self_coef=0.0, skip_self=False, w=None, out=None):
     return y
 
 
+def spmm_sum_sp(csr, x, self_coef=0.0, skip_self=False, out_sp=None):
+    """``spmm_sum`` with the result as an ``SpRows`` (the X operand of ``linear_sp``) and no fp32 copy."""
+    xp, ldx = _mat(x, "x")
+    n, d = x.shape
+    if n != csr.n:
+        raise ValueError("blgnn: x has %d rows, graph has %d nodes" % (n, csr.n))
+    sp = out_sp if out_sp is not None else SpRows(n, d, x.device)
+    call("blgnn_spmm_sum_sp", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, xp, ldx, n, d, float(self_coef),
+         int(bool(skip_self)), *_sp_args(sp, n, d), _stream())
+    return sp
+
+
+def gin_sp_preferred(csr, x, N, force=False):
+    """Shapes where a GIN layer runs as ``spmm_sum_sp`` + two ``linear_sp`` GEMMs instead of one fused launch: whole
+    256-column blocks on both sides, a molecular (low-degree) graph, enough rows for the 256 x 256 tiles -- and a width
+    the single-launch f16x3 layer does not have (d = 512: measured 76.8 vs 78.8 ms per step at configs[4] against the
+    in-kernel-split GEMMs; at d = 256 the single launch stays ahead: configs[3] 32.9 vs 34.0 ms, configs[2] even)."""
+    K = x.shape[1]
+    if force:                                              # (tests: any batch size, any whole-block width)
+        return K % 256 == 0 and N % 256 == 0 and 0 < K <= 2048 and 0 < N <= 2048 and x.stride(0) % 4 == 0 \
+            and x.data_ptr() % 16 == 0
+    return (N >= 512 and linear_sp_supported(x.shape[0], K, N) and linear_sp_supported(x.shape[0], N, N)
+            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and csr.nnz < 12 * max(csr.n, 1))
+
+
 def gin_layer_supported(csr, x, K, N):
     """Shapes the single-launch fused GIN layer is written for (include/blgnn.h), on
     low-degree (molecular) graphs; high-degree interaction graphs take the one-workgroup-

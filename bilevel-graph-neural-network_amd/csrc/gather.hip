@@ -169,13 +169,14 @@ __global__ void __launch_bounds__(256) k_gather(const GatherArgs A) {
                 }
             }
         }
-        if (MODE == MODE_RELU && LG == 64 && A.ys) {
+        if ((MODE == MODE_RELU || MODE == MODE_SUM) && LG == 64 && A.ys) {
             // sp output: chunk k of the row is exactly its k-th 256-column scale block, held by the 64 lanes of
-            // this wavefront -- block maximum (sums of relus are non-negative), power-of-two scale, two fp16 pieces
+            // this wavefront -- block maximum (sums of relus are non-negative; |.| for the plain sum), power-of-two
+            // scale, two fp16 pieces
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 if (!ok[k]) continue;                                  // wave-uniform (d4 is a multiple of 64)
-                float mx = fmaxf(fmaxf(acc[k].x, acc[k].y), fmaxf(acc[k].z, acc[k].w));
+                float mx = fmaxf(fmaxf(fabsf(acc[k].x), fabsf(acc[k].y)), fmaxf(fabsf(acc[k].z), fabsf(acc[k].w)));
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, WAVE));
                 float sc, inv;
@@ -846,6 +847,32 @@ extern "C" int blgnn_spmm_sum(const int32_t *rowptr, const int32_t *col, int64_t
     A.rowptr = rowptr; A.col = col; A.x = x; A.ldx = ldx; A.y = y; A.ldy = ldy; A.n = n; A.d = d;
     A.w = w; A.self_coef = self_coef; A.skip_self = skip_self;
     return dispatch<MODE_SUM>(A, nnz, true, (hipStream_t)stream, "spmm_sum");
+}
+
+extern "C" int blgnn_spmm_sum_sp(const int32_t *rowptr, const int32_t *col, int64_t nnz, const float *x, int64_t ldx,
+                                 int32_t n, int32_t d, float self_coef, int32_t skip_self, void *y_sp, int64_t ld_ysp,
+                                 uint8_t *y_spe, int64_t ld_yspe, void *stream) {
+    if (int rc = check_csr(rowptr, col, n, nnz, "spmm_sum_sp")) return rc;
+    BLGNN_CHECK_ARG(d >= 0 && (n == 0 || d == 0 || (x && y_sp && y_spe)), "spmm_sum_sp: null pointer");
+    BLGNN_CHECK_ARG(ldx >= d && ld_ysp >= 2 * (int64_t)d && ld_ysp % 8 == 0 && aligned16(y_sp) && ld_yspe >= d / SP_BLOCK,
+                    "spmm_sum_sp: bad leading dimensions / sp output planes");
+    if (d % SP_BLOCK != 0 || d > 2048 || ldx % 4 != 0 || !aligned16(x))
+        return fail(BLGNN_ERR_UNSUPPORTED, "spmm_sum_sp: needs d %% 256 == 0, d <= 2048 and 16-byte aligned rows (d=%d)", d);
+    if (n == 0 || d == 0) return BLGNN_OK;
+    GatherArgs A = {};
+    A.rowptr = rowptr; A.col = col; A.x = x; A.ldx = ldx; A.y = nullptr; A.ldy = d; A.n = n; A.d = d;
+    A.self_coef = self_coef; A.skip_self = skip_self;
+    A.ys = reinterpret_cast<_Float16 *>(y_sp); A.ldys = ld_ysp; A.ye = y_spe; A.ldye = ld_yspe;
+    hipStream_t s = (hipStream_t)stream;
+    // the sp epilogue lives in the one-wavefront-per-row kernel (a chunk of 64 lanes x 4 columns = one scale block)
+    const int d4 = d / 4;
+    if (d4 <= 64) launch_vec<MODE_SUM, 64, 1>(A, s);
+    else if (d4 <= 128) launch_vec<MODE_SUM, 64, 2>(A, s);
+    else if (d4 <= 192) launch_vec<MODE_SUM, 64, 3>(A, s);
+    else if (d4 <= 256) launch_vec<MODE_SUM, 64, 4>(A, s);
+    else if (d4 <= 320) launch_vec<MODE_SUM, 64, 5>(A, s);
+    else launch_vec<MODE_SUM, 64, 8>(A, s);
+    return launch_status("spmm_sum_sp");
 }
 
 extern "C" int blgnn_gcn_deg_inv_sqrt(const int32_t *rowptr, const int32_t *col, const float *w,

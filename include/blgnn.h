@@ -101,6 +101,13 @@ int blgnn_spmm_sum(const int32_t *rowptr, const int32_t *col, int64_t nnz, const
                    int32_t n, int32_t d, float self_coef, int32_t skip_self,
                    void *stream);
 
+/* The same aggregation with the result in the sp format of blgnn_linear_sp (below) and no fp32 copy: the GIN layer
+ * as aggregation + two pre-split GEMMs (model/layers.py:9-63 at the widths the single-launch f16x3 layer does not
+ * cover: d = 512).  d % 256 == 0, d <= 2048, 16-byte aligned x rows. */
+int blgnn_spmm_sum_sp(const int32_t *rowptr, const int32_t *col, int64_t nnz, const float *x, int64_t ldx,
+                      int32_t n, int32_t d, float self_coef, int32_t skip_self, void *y_sp, int64_t ld_ysp,
+                      uint8_t *y_spe, int64_t ld_yspe, void *stream);
+
 /* One whole GIN NodeEmbedding layer in ONE launch: model/layers.py:26-31,51-57.
  *   y = affine( act( act( agg @ w1 + b1 ) @ w2 + b2 ) ),
  *   agg_i = (1 + eps) x_i + sum_{j in row i, j != i} x_j

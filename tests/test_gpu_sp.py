@@ -226,7 +226,9 @@ def test_gmn_model_with_sp_pipeline_forced(device, d, shape, dataset, edge_types
 
     def forced(*a, **k):
         k.setdefault("gmn_sp", "force")
-        return orig(*a, **k)
+        f = orig(*a, **k)
+        f.gin_sp = "force"            # GIN layers with K, N on 256-column blocks: aggregation into sp + two pre-split GEMMs
+        return f
 
     blgnn.make_flags = forced
     try:
@@ -334,3 +336,40 @@ def test_gmn_pooled_tail_equals_the_readout_of_node_rows(device):
     assert tuple(a[6].shape) == tuple(b[6].shape) == (G, 768)
     assert max_err(a[6], b[6].cpu()) < 0.1 * TOL                       # the readout [G, 3 D]
     assert max_err(a[-1], b[-1].cpu()) < 0.1 * TOL                     # pair scores
+
+
+@pytest.mark.parametrize("d", [256, 512])
+def test_spmm_sum_sp_and_gin_as_presplit_gemms(device, d):
+    """blgnn_spmm_sum_sp: (1 + eps) x_i + sum_j x_j straight into the sp format == the fp32 aggregation to 22 bits per
+    256-column block; then the whole GIN layer as aggregation + two pre-split GEMMs with eval-BN, the readout on the
+    second GEMM's epilogue, against fp64 (model/layers.py:9-63)"""
+    g = torch.Generator().manual_seed(40 + d)
+    n = 3000
+    x = torch.randn(n, d, generator=g)
+    src = torch.randint(0, n, (2 * n,), generator=g)
+    dst = (src + torch.randint(1, 40, (2 * n,), generator=g)) % n
+    ei = torch.stack([torch.cat([src, dst]), torch.cat([dst, src])])
+    ei = torch.unique(ei, dim=1)
+    dv = lambda t: t.to(device)
+    csr = ops.csr_from_edge_index(dv(ei), n)
+    ref_agg = 1.3 * x.double()
+    ref_agg.index_add_(0, ei[0], x.double()[ei[1]])
+    agg_sp = ops.spmm_sum_sp(csr, dv(x), self_coef=1.3, skip_self=True)
+    assert _row_rel(ops.join_rows_sp(agg_sp), ref_agg) < 2.0 ** -20
+    w1, w2 = torch.randn(d, d, generator=g) / d ** 0.5, torch.randn(d, d, generator=g) / d ** 0.5
+    b1, b2 = torch.randn(d, generator=g) * 0.1, torch.randn(d, generator=g) * 0.1
+    scale, shift = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    h = torch.relu(ref_agg @ w1.double() + b1.double())
+    ref = torch.relu(h @ w2.double() + b2.double()) * scale.double() + shift.double()
+    sizes = [30] * (n // 30)
+    seg = torch.tensor([0] + sizes).cumsum(0).to(torch.int32)
+    rg = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).to(torch.int32)
+    pooled = torch.zeros(len(sizes), d, device=device)
+    h_sp = ops.SpRows(n, d, device)
+    ops.linear_sp(agg_sp, dv(w1), dv(b1), act="relu", out_sp=h_sp)
+    y, _ = ops.linear_sp(h_sp, dv(w2), dv(b2), act="relu", bn_scale=dv(scale), bn_shift=dv(shift), f32=True,
+                         pool=(dv(rg), dv(seg), pooled, "mean"))
+    assert max_err(y, ref) < TOL
+    assert max_err(pooled, ref.view(len(sizes), 30, d).mean(1)) < TOL
+    with pytest.raises((ValueError, NotImplementedError)):
+        ops.spmm_sum_sp(csr, dv(x)[:, :192].contiguous())
