@@ -25,6 +25,12 @@
 
 namespace blgnn {
 
+#ifdef GIN_STAMP
+__device__ unsigned long long g_gin_stamps[16];    // diagnostics: 100 MHz ticks at the phase boundaries of one workgroup
+#define GIN_TICK(i) do { if (N == 256 && blockIdx.x == gridDim.x / 2 + 5 && threadIdx.x == 0) g_gin_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GIN_TICK(i) do { } while (0)
+#endif
 constexpr int HCOLS = 512;       // column indices of a tile kept in LDS (64 rows x mean degree 2.1 = 136)
 
 // ---- weight packing: W[K,N] fp32 -> header + [2][Kp/8][N][8] fp16, scaled by a power of two -------------
@@ -117,10 +123,22 @@ __device__ __forceinline__ void load_b_h3(f16x8 (&dst)[2][2], hrsrc_t W, int Kp,
         }
 }
 
-constexpr int HRING = 3;         // weight chunk buffers (16 VGPRs each), two chunks ahead of the MFMAs
+// weight chunk buffers (16 VGPRs each): HR - 1 chunks are requested ahead of the MFMAs.  N = 128 (128 VGPRs, four
+// workgroups per CU): 3.  N = 256 (one 512-thread workgroup per CU): GIN_HR256 -- depths 3 / 4 / 5 / 6 (209 .. 255 VGPRs,
+// no spills) measured 878 / 894 / 866-885 / 892 us on 499 k rows: the weight stream is not what the layer waits for.
+// Where a 64-row tile's 26-27 us go at K = N = 256 (GIN_STAMP build, scratch/gin_stamp.hip; one workgroup per CU, so the
+// phases of a tile are strictly serial): rows + CSR slice staged 4.7-5.0, gather + row scale + split 7.2 (the out-of-tile
+// neighbours of the molecule that straddles the tile edge are fetched from L2 inside the passes: two exposed round
+// trips), GEMM1 3.7-4.0 (matrix-core bound: 3.4), act + row maxima + barrier 2.2, split of the hidden tile 0.9-1.0,
+// GEMM2 4.9-5.0 (its first weight chunks are requested only when GEMM1 has released the ring), staging + row stores 2.3-2.7.
+#ifndef GIN_HR256
+#define GIN_HR256 3
+#endif
+template <int N> struct HRing { static constexpr int V = N == 256 ? GIN_HR256 : 3; };
 
 template <int N>
-__device__ __forceinline__ void h3_prefetch(f16x8 (&w)[HRING][2][2], hrsrc_t Wp, int Kp, unsigned lane_off) {
+__device__ __forceinline__ void h3_prefetch(f16x8 (&w)[HRing<N>::V][2][2], hrsrc_t Wp, int Kp, unsigned lane_off) {
+    constexpr int HRING = HRing<N>::V;
 #pragma unroll
     for (int u = 0; u < HRING - 1; ++u)
         if (u * KC < Kp) load_b_h3<N>(w[u], Wp, Kp, u * KC, lane_off);
@@ -130,7 +148,8 @@ __device__ __forceinline__ void h3_prefetch(f16x8 (&w)[HRING][2][2], hrsrc_t Wp,
 // lane ends up with n = n_base + 8 (r >> 2) + 4 fh + (r & 3), m = 32 mt + fi)
 template <int MT, int N>
 __device__ __forceinline__ void gemm_h3(f32x16 (&acc0)[MT], f32x16 (&acc1)[MT], const char *Ap, int sa, hrsrc_t Wp,
-                                        int Kp, unsigned lane_off, int fi, int fh, f16x8 (&w)[HRING][2][2]) {
+                                        int Kp, unsigned lane_off, int fi, int fh, f16x8 (&w)[HRing<N>::V][2][2]) {
+    constexpr int HRING = HRing<N>::V;
     const int piece_bytes = MT * 32 * sa;
     const char *arow = Ap + fi * sa + fh * 16;                   // lane (row fi, k half fh)
     for (int kc = 0; kc < Kp; kc += HRING * KC) {
@@ -171,6 +190,7 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
     constexpr int N4 = N / 4;
     extern __shared__ float4 lds4[];
     char *lds = reinterpret_cast<char *>(lds4);
+    GIN_TICK(0);
     const int sa = A.Kp * 2 + 16;                   // aggregated piece row stride (bytes)
     // region 0: aggregated pieces [2][XBM][sa], later the fp32 output staging tile [XBM][N+4]
     // region 1: staged fp32 input rows [XBM][K], later the hidden pieces [2][XBM][SH]
@@ -217,7 +237,7 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
         const int row = m0 + (p * NW + wid) * RPW + sub;
         xin[p] = (ok && row < A.n) ? load_x4(row) : f4_zero();
     }
-    f16x8 wfrag[HRING][2][2];
+    f16x8 wfrag[HRing<N>::V][2][2];
     h3_prefetch<N>(wfrag, W1, A.Kp, lane_off);
     const float w1inv = *reinterpret_cast<const float *>(A.w1p), w2inv = *reinterpret_cast<const float *>(A.w2p);
     const int e_lo = A.rowptr[m0];                                   // uniform addresses: scalar loads
@@ -256,6 +276,7 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
         *reinterpret_cast<_Float16 *>(Ap + q * XBM * sa + m * sa + k * 2) = (_Float16)0.f;
     }
     lds_barrier();
+    GIN_TICK(1);
 
     // ---- (1) gather from LDS (+ out-of-tile rows from L2, FB passes per round trip), scale, split, park --------
     constexpr int FBMAX = XBM == 64 ? 4 : 2;       // 16 VGPRs per pass in flight
@@ -327,6 +348,7 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
         }
     }
     lds_barrier();
+    GIN_TICK(2);
 
     // ---- (2) hidden = act(agg @ W1 + b1): row maxima -> scale -> split -> park -----------------------------------
     f32x16 acc0[MT], acc1[MT];
@@ -346,6 +368,7 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
                                                             : f4_zero();
     }
     gemm_h3<MT, N>(acc0, acc1, Ap, sa, W1, A.Kp, lane_off, fi, fh, wfrag);
+    GIN_TICK(9);
     h3_prefetch<N>(wfrag, W2, N, lane_off);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -365,6 +388,7 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
         if (fh == 0) atomicMax(&hmax[mt * 32 + fi], __float_as_uint(hm));   // across the four column waves
     }
     lds_barrier();
+    GIN_TICK(3);
     float hinv[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -382,6 +406,7 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
         }
     }
     lds_barrier();
+    GIN_TICK(4);
 
     // ---- (3) y = affine(act(hidden @ W2 + b2)) -> LDS staging -> row stores ---------------------------------
     zero();
@@ -396,6 +421,7 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
         if (A.epi.bn_scale && A.epi.bn_shift) psh[g] = *reinterpret_cast<const float4 *>(A.epi.bn_shift + c);
     }
     gemm_h3<MT, N>(acc0, acc1, Hp, SH, W2, N, lane_off, fi, fh, wfrag);
+    GIN_TICK(10);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const float rs = hinv[mt] * w2inv;
@@ -415,6 +441,7 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
         }
     }
     lds_barrier();
+    GIN_TICK(5);
     for (int idx = threadIdx.x; idx < XBM * N4; idx += NTH) {
         const int m = idx / N4, c4 = idx % N4;
         const int row = m0 + m;
@@ -441,6 +468,7 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
             }
         }
     }
+    GIN_TICK(8);
     // ---- (4) fused readout: per-graph column sums of the staged tile, one atomic per (graph, column) and tile.
     // Rows are sorted by graph, so a tile touches few graphs (DrugBank: 27 atoms per molecule, ~2 per tile) and a
     // graph spans few tiles; with <= 2 contributions per graph the sum does not depend on their order.
