@@ -7,8 +7,9 @@
 #include "../gin_h3.hip"
 #include "../runtime.hip"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
-int main() {
-    const int n = 498729 / 40 * 40, K = 256, N = 256, per = 40;
+int main(int argc, char **argv) {
+    const int per = argc > 1 ? atoi(argv[1]) : 40;              // atoms per molecule (64: no molecule straddles a 64-row tile)
+    const int n = 498729 / per * per, K = 256, N = 256;
     std::vector<int> rp(n + 1), col;
     for (int i = 0; i < n; ++i) {                        // chains of 40 atoms + a few ring closures: ~2.1 edges per atom
         rp[i] = (int)col.size();

@@ -127,10 +127,11 @@ __device__ __forceinline__ void load_b_h3(f16x8 (&dst)[2][2], hrsrc_t W, int Kp,
 // workgroups per CU): 3.  N = 256 (one 512-thread workgroup per CU): GIN_HR256 -- depths 3 / 4 / 5 / 6 (209 .. 255 VGPRs,
 // no spills) measured 878 / 894 / 866-885 / 892 us on 499 k rows: the weight stream is not what the layer waits for.
 // Where a 64-row tile's 26-27 us go at K = N = 256 (GIN_STAMP build, csrc/diag/gin_stamp.hip; one workgroup per CU, so the
-// phases of a tile are strictly serial): rows + CSR slice staged 4.7-5.0, gather + row scale + split 7.2 (the out-of-tile
-// neighbours of the molecule that straddles the tile edge are fetched from L2 inside the passes: two exposed round
-// trips), GEMM1 3.7-4.0 (matrix-core bound: 3.4), act + row maxima + barrier 2.2, split of the hidden tile 0.9-1.0,
-// GEMM2 4.9-5.0 (its first weight chunks are requested only when GEMM1 has released the ring), staging + row stores 2.3-2.7.
+// phases of a tile are strictly serial): rows + CSR slice staged 4.7-5.0, gather + row scale + split 7.2 (NOT the
+// out-of-tile neighbours: with 64-atom molecules, none of which straddles a tile, the phase still takes 7.2 -- it is
+// eight passes per wavefront of LDS reads, a 64-lane row maximum and the two-piece split, ~80 vector instructions per
+// row at two wavefronts per SIMD), GEMM1 3.7-4.0 (matrix-core bound: 3.4), act + row maxima + barrier 2.2, split of the
+// hidden tile 0.9-1.0, GEMM2 4.9-5.0, staging + row stores 2.3-2.7.
 #ifndef GIN_HR256
 #define GIN_HR256 3
 #endif
