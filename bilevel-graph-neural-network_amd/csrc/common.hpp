@@ -65,6 +65,40 @@ __device__ __forceinline__ T group_max(T v, int width) {
     return v;
 }
 
+// The same reductions for a COMPILE-TIME group of W adjacent lanes (W = 2 .. 64, aligned), every lane gets the result.
+// __shfl_xor compiles to ds_bpermute_b32 on this target -- an LDS-crossbar round trip per step, six dependent ones for a
+// 64-lane reduction (~500 cycles).  Inside a 16-lane row the butterfly runs on DPP instead (quad_perm for xor 1 and 2;
+// after those every quad is uniform, so row_half_mirror pairs quads and row_mirror pairs half rows exactly as xor 4 and
+// xor 8 would), and the four row results of a wavefront are combined from v_readlane scalars -- the association is
+// that of the xor butterfly, so sums come out bit for bit the same.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int W, typename OP>
+__device__ __forceinline__ float lanes_reduce(float v, OP op) {
+    static_assert(W == 2 || W == 4 || W == 8 || W == 16 || W == 32 || W == 64, "group width");
+    if (W >= 2) v = op(v, dpp_f32<0xB1>(v));             // quad_perm [1, 0, 3, 2]
+    if (W >= 4) v = op(v, dpp_f32<0x4E>(v));             // quad_perm [2, 3, 0, 1]
+    if (W >= 8) v = op(v, dpp_f32<0x141>(v));            // row_half_mirror
+    if (W >= 16) v = op(v, dpp_f32<0x140>(v));           // row_mirror
+    if (W == 32) v = op(v, __shfl_xor(v, 16, WAVE));
+    if (W == 64) {
+        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+        const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+        v = op(op(r0, r1), op(r2, r3));
+    }
+    return v;
+}
+template <int W> __device__ __forceinline__ float lanes_max(float v) {
+    return lanes_reduce<W>(v, [](float a, float b) { return fmaxf(a, b); });
+}
+template <int W> __device__ __forceinline__ float lanes_sum(float v) {
+    return lanes_reduce<W>(v, [](float a, float b) { return a + b; });
+}
+
 // per-channel epilogue shared by the conv kernels and the GEMM:
 //   v -> act(v + bias[c]) * bn_scale[c] + bn_shift[c]
 struct Epilogue {

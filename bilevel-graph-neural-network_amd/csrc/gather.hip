@@ -177,8 +177,7 @@ __global__ void __launch_bounds__(256) k_gather(const GatherArgs A) {
             for (int k = 0; k < CH; ++k) {
                 if (!ok[k]) continue;                                  // wave-uniform (d4 is a multiple of 64)
                 float mx = fmaxf(fmaxf(fabsf(acc[k].x), fabsf(acc[k].y)), fmaxf(fabsf(acc[k].z), fabsf(acc[k].w)));
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, WAVE));
+                mx = lanes_max<64>(mx);
                 float sc, inv;
                 pow2_scale(mx, sc, inv);
                 if (l == 0) A.ye[(int64_t)row * A.ldye + k] = sp_exp_of(inv);
@@ -194,8 +193,7 @@ __global__ void __launch_bounds__(256) k_gather(const GatherArgs A) {
 #pragma unroll
             for (int k = 0; k < CH; ++k)
                 if (ok[k]) mx = fmaxf(mx, fmaxf(fmaxf(acc[k].x, acc[k].y), fmaxf(acc[k].z, acc[k].w)));
-#pragma unroll
-            for (int off = 1; off < LG; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, WAVE));
+            mx = lanes_max<LG>(mx);
             if (l == 0) atomicMax(reinterpret_cast<unsigned *>(A.amax) + row, __float_as_uint(mx));
         }
 #pragma unroll

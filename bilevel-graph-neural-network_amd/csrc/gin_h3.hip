@@ -333,8 +333,7 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
             }
             // row maximum over the LG lanes of the row -> power-of-two scale
             float amax = ok ? fmaxf(fmaxf(fabsf(accv[pp].x), fabsf(accv[pp].y)), fmaxf(fabsf(accv[pp].z), fabsf(accv[pp].w))) : 0.f;
-#pragma unroll
-            for (int off = 1; off < LG; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off, WAVE));
+            amax = lanes_max<LG>(amax);
             float scale, inv;
             pow2_scale(amax, scale, inv);
             if (l == 0) ainv[m] = inv;
@@ -456,8 +455,7 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
         if (A.y_amax || (N == 256 && A.ysp)) {
             // the N4 lanes that store one row sit in one wavefront (N4 = 32 or 64): their maximum is the row's
             float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-#pragma unroll
-            for (int off = 1; off < N4; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, WAVE));
+            mx = lanes_max<N4>(mx);
             if (live && c4 == 0 && A.y_amax) A.y_amax[row] = mx;
             if (N == 256 && A.ysp && live) {
                 // the row is one 256-column scale block: the GMN propagator's GEMMs read it from here
