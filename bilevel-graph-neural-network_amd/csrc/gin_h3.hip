@@ -309,20 +309,31 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
                 f4_fma(accv[pp], use ? 1.f : 0.f, u);
             }
         }
-        float4 fu[FB][4];
+        // out-of-tile neighbours (the molecule that straddles the tile edge): most wavefronts have none in a group of
+        // passes -- a wave-uniform test keeps their 16 zero-filled rows and 16 row additions out of the instruction stream
+        bool has_far = false;
 #pragma unroll
         for (int pp = 0; pp < FB; ++pp)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                fu[pp][q] = f4_zero();
-                if (far[pp][q] >= 0) fu[pp][q] = load_x4(far[pp][q]);
-            }
+            for (int q = 0; q < 4; ++q) has_far |= far[pp][q] >= 0;
+        if (__builtin_amdgcn_ballot_w64(has_far) != 0) {
+            float4 fu[FB][4];
+#pragma unroll
+            for (int pp = 0; pp < FB; ++pp)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    fu[pp][q] = f4_zero();
+                    if (far[pp][q] >= 0) fu[pp][q] = load_x4(far[pp][q]);
+                }
+#pragma unroll
+            for (int pp = 0; pp < FB; ++pp)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f4_add(accv[pp], fu[pp][q]);
+        }
 #pragma unroll
         for (int pp = 0; pp < FB; ++pp) {
             const int m = ((pg + pp) * NW + wid) * RPW + sub;
             const int row = m0 + m;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) f4_add(accv[pp], fu[pp][q]);
             if (ok) {
                 const int e0 = rp[m], cnt = rp[m + 1] - e0;
                 const int first = cols_in_lds ? 4 : 0;
