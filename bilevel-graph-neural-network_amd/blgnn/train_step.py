@@ -10,6 +10,10 @@ scorer reads and their labels: 2 x 8 B + 4 B per pair, copied into static device
 Everything the captured region executes is the SAME code the eager step executes (the modules' train-mode forwards, the
 autograd nodes of blgnn/autograd.py, torch's optimizer): capture records the launches, it does not change them.
 ``capture=False`` runs the identical step eagerly (tests compare the two).
+
+Scope: one GPU, the bi-level models (lower sweep + interaction level), optimizers whose ``step()`` launches no host-side
+decision (SGD, and torch's ``capturable`` variants).  Data-parallel training keeps the eager iteration: the gradient and
+BatchNorm-statistics all-reduces of ``autograd.set_batch_norm_sync`` are driven from the host between kernels.
 """
 
 import numpy as np
