@@ -78,6 +78,10 @@ __device__ __forceinline__ float dpp_f32(float v) {
 template <int W, typename OP>
 __device__ __forceinline__ float lanes_reduce(float v, OP op) {
     static_assert(W == 2 || W == 4 || W == 8 || W == 16 || W == 32 || W == 64, "group width");
+#ifdef BLGNN_NO_DPP                                       // (A/B switch: the ds_bpermute butterfly)
+    for (int o = 1; o < W; o <<= 1) v = op(v, __shfl_xor(v, o, WAVE));
+    return v;
+#endif
     if (W >= 2) v = op(v, dpp_f32<0xB1>(v));             // quad_perm [1, 0, 3, 2]
     if (W >= 4) v = op(v, dpp_f32<0x4E>(v));             // quad_perm [2, 3, 0, 1]
     if (W >= 8) v = op(v, dpp_f32<0x141>(v));            // row_half_mirror

@@ -373,3 +373,24 @@ def test_spmm_sum_sp_and_gin_as_presplit_gemms(device, d):
     assert max_err(pooled, ref.view(len(sizes), 30, d).mean(1)) < TOL
     with pytest.raises((ValueError, NotImplementedError)):
         ops.spmm_sum_sp(csr, dv(x)[:, :192].contiguous())
+
+
+def test_gmn_sp_pipeline_without_side_stream(device):
+    """the same forced sp pipeline with the attention on the launch stream (FLAGS.gmn_overlap_match = False): shared
+    prefix, K-split, pooled readout and the in-line attention + split against the fp64 oracle"""
+    from test_gpu_configs import _gmn_model_vs_oracle
+    import blgnn.config as cfg
+    orig = cfg.make_flags
+
+    def forced(*a, **k):
+        k.setdefault("gmn_sp", "force")
+        f = orig(*a, **k)
+        f.gmn_overlap_match = False
+        return f
+
+    blgnn.make_flags = forced
+    try:
+        preds = _gmn_model_vs_oracle(device, 256, 100, 1200, 200, 77, "drugcombo", 2, "drugcombo")
+    finally:
+        blgnn.make_flags = orig
+    assert preds.shape[0] == 200
