@@ -80,6 +80,7 @@ SIGNATURES = {
     "blgnn_stream_destroy": [_p],
     "blgnn_col_reduce": [_p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, _f32, _p, _p, _p],
     "blgnn_grad_weight": [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p],
+    "blgnn_bn_finalize": [_p, _p, _i32, _f32, _f32, _f32, _p, _p, _p, _p],
     "blgnn_bn_apply": [_p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p],
     "blgnn_bn_backward": [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i32, _i32, _i64, _p, _i64, _p],
     "blgnn_act_backward": [_p, _i64, _p, _i64, _i32, _p, _i32, _i32, _p, _i64, _p],

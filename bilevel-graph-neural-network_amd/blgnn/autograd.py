@@ -217,15 +217,20 @@ def set_batch_norm_sync(reduce_fn):
 
 class _BatchNormTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, stats_out, act="identity"):
+    def forward(ctx, x, gamma, beta, eps, stats_out, act="identity", running=None):
         _check_act(act)
         x = x.detach()
         M, N = x.shape
         red = _SYNC["reduce"]
+        rstd = None
         if red is None:
             count = float(M)
             mean = ops.col_reduce(x, "sum", scale=1.0 / M)
             var = ops.col_reduce(x, "sqdev", mean=mean, scale=1.0 / M)            # biased, two-pass
+            if running is not None:
+                # rstd and torch's running-statistics update (momentum form, unbiased variance) in one launch
+                rm, rv, mom = running
+                rstd = ops.bn_finalize(mean, var, eps, mom, count / max(count - 1.0, 1.0), rm, rv)
         else:
             # two-pass over the union of the ranks' rows: global sum -> mean, global centred squares -> variance
             buf = torch.empty(N + 1, dtype=torch.float32, device=x.device)
@@ -235,10 +240,12 @@ class _BatchNormTrain(torch.autograd.Function):
             count = float(buf[N])
             mean = (buf[:N] / count).contiguous()
             var = red(ops.col_reduce(x, "sqdev", mean=mean)) / count
-        rstd = torch.rsqrt(var + eps)                                             # [N] vector glue
+        fused = rstd is not None
+        if not fused:
+            rstd = torch.rsqrt(var + eps)                                         # [N] vector glue
         y = ops.bn_apply(x, mean, rstd, None if gamma is None else gamma.detach(),
                          None if beta is None else beta.detach(), act=act)
-        stats_out.extend((mean, var, count))
+        stats_out.extend((mean, var, count, fused))                               # fused: running statistics already updated
         ctx.save_for_backward(x, mean, rstd, gamma.detach() if gamma is not None else None,
                               y if act != "identity" else None)
         ctx.has_affine = gamma is not None
@@ -262,7 +269,7 @@ class _BatchNormTrain(torch.autograd.Function):
             tot = both if red is None else red(both.clone())                     # dx needs the sums over ALL rows
             dx = ops.bn_backward(dy, x, mean, rstd, gamma, tot[1], tot[0], count=ctx.count)
         # the parameter gradients stay local sums (a data-parallel wrapper reduces parameter gradients itself)
-        return dx, (dgamma if ctx.has_affine else None), (dbeta if ctx.has_affine else None), None, None, None
+        return dx, (dgamma if ctx.has_affine else None), (dbeta if ctx.has_affine else None), None, None, None, None
 
 
 def batch_norm_train(x, bn, act="identity"):
@@ -270,14 +277,19 @@ def batch_norm_train(x, bn, act="identity"):
     update (momentum form, unbiased variance) torch performs as a side effect.  ``act``: the activation that
     follows the BatchNorm inside an MLP (model/layers_util.py:51-54), fused into the same kernels."""
     stats = []
-    y = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps, stats, act)
-    if bn.track_running_stats and bn.running_mean is not None:
-        mean, var, M = stats
+    track = bn.track_running_stats and bn.running_mean is not None
+    running = None
+    if track and bn.momentum is not None:
+        running = (bn.running_mean, bn.running_var, float(bn.momentum))           # updated inside the forward's launch
+    y = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps, stats, act, running)
+    if track:
+        mean, var, M, updated = stats
         with torch.no_grad():
             bn.num_batches_tracked += 1
-            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-            bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
-            bn.running_var.mul_(1.0 - mom).add_(var * (M / max(M - 1.0, 1.0)), alpha=mom)
+            if not updated:                                                       # (rank-synchronised statistics, or a
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)   # cumulative average)
+                bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
+                bn.running_var.mul_(1.0 - mom).add_(var * (M / max(M - 1.0, 1.0)), alpha=mom)
     return y
 
 

@@ -845,6 +845,15 @@ def col_reduce(a, mode="sum", b=None, mean=None, rstd=None, scale=1.0, out=None)
     return out
 
 
+def bn_finalize(mean, var, eps, momentum=0.0, unbias=1.0, running_mean=None, running_var=None):
+    """rstd = 1 / sqrt(var + eps) and (optionally) BatchNorm's running-statistics update, one launch.  -> rstd [N]"""
+    N = var.shape[0]
+    rstd = torch.empty(N, dtype=torch.float32, device=var.device)
+    call("blgnn_bn_finalize", _vec(mean, "mean"), _vec(var, "var", optional=False), N, float(eps), float(momentum),
+         float(unbias), rstd.data_ptr(), _vec(running_mean, "running_mean"), _vec(running_var, "running_var"), _stream())
+    return rstd
+
+
 def bn_apply(x, mean, rstd, gamma=None, beta=None, out=None, act="identity"):
     xp, ldx = _mat(x, "x")
     y = _out(out, x.shape[0], x.shape[1], x)

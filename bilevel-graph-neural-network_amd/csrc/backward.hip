@@ -81,6 +81,20 @@ __global__ void __launch_bounds__(256) k_col_final(const float *__restrict__ par
         out[c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) * scale;
 }
 
+// the [N]-vector step between the two BatchNorm passes, one launch instead of eight pointwise ones:
+// rstd = 1 / sqrt(var + eps); running_mean <- (1 - m) running_mean + m mean; running_var <- (1 - m) running_var + m var c
+// (c = M / (M - 1): torch's unbiased running variance; torch.nn.BatchNorm1d, train mode)
+__global__ void k_bn_finalize(const float *__restrict__ mean, const float *__restrict__ var, int N, float eps, float mom,
+                              float unbias, float *__restrict__ rstd, float *__restrict__ run_mean,
+                              float *__restrict__ run_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const float v = var[c];
+    rstd[c] = 1.f / sqrtf(v + eps);
+    if (run_mean) run_mean[c] = fmaf(mom, mean[c], (1.f - mom) * run_mean[c]);
+    if (run_var) run_var[c] = fmaf(mom, v * unbias, (1.f - mom) * run_var[c]);
+}
+
 // y = (x - mean) * rstd * gamma + beta
 __global__ void k_bn_apply(const float *__restrict__ x, int64_t ldx, const float *__restrict__ mean,
                            const float *__restrict__ rstd, const float *__restrict__ gamma,
@@ -307,6 +321,16 @@ extern "C" int blgnn_grad_weight(const float *g, int64_t ldg, const float *x, in
                            M, O, I, rows, scratch);
     hipLaunchKernelGGL(k_col_final, dim3((O * I + 63) / 64), dim3(256), 0, s, scratch, chunks, O * I, 1.f, dw);
     return launch_status("grad_weight");
+}
+
+extern "C" int blgnn_bn_finalize(const float *mean, const float *var, int32_t N, float eps, float momentum, float unbias,
+                                 float *rstd, float *running_mean, float *running_var, void *stream) {
+    BLGNN_CHECK_ARG(N >= 0, "bn_finalize: negative size");
+    if (N == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(var && rstd && ((!running_mean && !running_var) || mean), "bn_finalize: null pointer");
+    hipLaunchKernelGGL(k_bn_finalize, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, var, N, eps, momentum,
+                       unbias, rstd, running_mean, running_var);
+    return launch_status("bn_finalize");
 }
 
 extern "C" int blgnn_bn_apply(const float *x, int64_t ldx, const float *mean, const float *rstd, const float *gamma,

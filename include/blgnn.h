@@ -514,6 +514,13 @@ int64_t blgnn_grad_weight_scratch_elems(int32_t M, int32_t O, int32_t I);
 int blgnn_grad_weight(const float *g, int64_t ldg, const float *x, int64_t ldx, int32_t M, int32_t O,
                       int32_t I, float *scratch, float *dw, void *stream);
 
+/* The [N]-vector step between the two statistics passes and the normalisation of train-mode BatchNorm1d
+ * (model/layers.py:39-40,56-57 under src/train.py:177-182), one launch: rstd = 1 / sqrt(var + eps) and, when the
+ * running buffers are given, torch's momentum update running = (1 - m) running + m {mean, var * unbias}
+ * (unbias = M / (M - 1)). */
+int blgnn_bn_finalize(const float *mean, const float *var, int32_t N, float eps, float momentum, float unbias,
+                      float *rstd, float *running_mean, float *running_var, void *stream);
+
 /* Train-mode BatchNorm1d forward: y = act((x - mean) * rstd * gamma + beta) (gamma / beta nullable;
  * act = the activation that follows the BatchNorm in MLP: model/layers_util.py:51-54). */
 int blgnn_bn_apply(const float *x, int64_t ldx, const float *mean, const float *rstd,

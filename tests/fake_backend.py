@@ -203,6 +203,14 @@ def bn_apply(x, mean, rstd, gamma=None, beta=None, out=None, act="identity"):
     return _put(out, oracle.apply_act(y, act, None))
 
 
+def bn_finalize(mean, var, eps, momentum=0.0, unbias=1.0, running_mean=None, running_var=None):
+    if running_mean is not None:
+        running_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+    if running_var is not None:
+        running_var.mul_(1.0 - momentum).add_(var * unbias, alpha=momentum)
+    return torch.rsqrt(var + eps)
+
+
 def bn_backward(dy, x, mean, rstd, gamma, dgamma, dbeta, out=None, count=None):
     m = float(count if count is not None else x.shape[0])
     xh = (x - mean) * rstd
@@ -215,7 +223,7 @@ NAMES = ["csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear", "li
          "gin_layer",
          "gin_layer_supported", "gin_layer_x6_supported", "gat_conv", "gcn_conv",
          "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum", "row_degree", "pair_gather_normalize", "link_pred_head",
-         "l2_normalize_rows", "scatter_rows", "require_device", "col_reduce", "bn_apply", "bn_backward", "hadamard"]
+         "l2_normalize_rows", "scatter_rows", "require_device", "col_reduce", "bn_apply", "bn_finalize", "bn_backward", "hadamard"]
 
 
 def install(monkeypatch):
