@@ -210,13 +210,14 @@ __global__ void k_pair_scatter_add(const float *__restrict__ dcat, int64_t ldc, 
 // fragment and x[row, 32 ti + fi] as the B fragment: both coalesced, no transpose, no LDS), partials go to scratch and
 // k_col_final adds them in a fixed order (deterministic).  The forward GEMM kernels are shaped for the opposite case.
 constexpr int GW_ROWS = 1024;           // most rows per chunk
-// rows per chunk: at least ~one workgroup per CU (37 k x 128 x 128: 290 chunks of 128 rows instead of 37 of 1 024, whose
-// 64 dependent operand round trips each made the launch 306 us)
+// rows per chunk: ONE workgroup per CU, all of them equally long (37 k x 128 x 128: 256 chunks of 144 rows.  37 chunks of
+// 1 024 rows ran 64 dependent operand round trips each: 306 us per launch; 290 chunks of 128 rows: 46 us, because the 34
+// workgroups beyond the 256th made a second round as long as the first)
 static inline int gw_rows(int M, int O, int I) {
     const int tiles = ((O + 127) / 128) * ((I + 127) / 128);
-    const int want = (512 + tiles - 1) / tiles;                        // chunks wanted
-    int r = ((M + want - 1) / want + 15) / 16 * 16;
-    return r < 128 ? 128 : (r > GW_ROWS ? GW_ROWS : r);
+    const int want = tiles >= 256 ? 1 : 256 / tiles;                   // chunks wanted
+    int r = (M + want - 1) / want;
+    return r < 64 ? 64 : (r > GW_ROWS ? GW_ROWS : r);
 }
 typedef float f32x16g __attribute__((ext_vector_type(16)));
 
@@ -240,18 +241,20 @@ __global__ void __launch_bounds__(256) k_grad_weight(const float *__restrict__ g
     const int ic[2] = {min(i0 + fi, I - 1), min(i0 + 32 + fi, I - 1)};
     if (o0 < O && i0 < I) {
         // eight K steps (16 rows) of operands are requested before the first MFMA of the group: the loop is a chain of
-        // memory round trips otherwise (243 us per launch on 37 k rows; the products themselves need ~30 us)
-        for (int k = r0; k < r1; k += 16) {
-            float a0[8], a1[8], b0[8], b1[8];
+        // memory round trips otherwise (243 us per launch on 37 k rows; the products themselves need ~30 us; sixteen steps in
+        // flight measured the same: what the loop pays for is its 4-byte operand loads, see k_grad_weight_lds)
+        constexpr int GU = 8;                               // MFMA K steps (2 rows each) whose operands are in flight together
+        for (int k = r0; k < r1; k += 2 * GU) {
+            float a0[GU], a1[GU], b0[GU], b1[GU];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < GU; ++u) {
                 const int row = min(k + 2 * u + fh, r1 - 1);
                 const float live = (k + 2 * u + fh) < r1 ? 1.f : 0.f;
                 const float *gr = g + (int64_t)row * ldg, *xr = x + (int64_t)row * ldx;
                 a0[u] = gr[oc[0]] * live; a1[u] = gr[oc[1]] * live; b0[u] = xr[ic[0]]; b1[u] = xr[ic[1]];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < GU; ++u) {
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], acc[1][0], 0, 0, 0);
@@ -267,6 +270,73 @@ __global__ void __launch_bounds__(256) k_grad_weight(const float *__restrict__ g
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = o0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * fh, i = i0 + 32 * b + fi;
+                if (o < O && i < I) dst[(int64_t)o * I + i] = acc[a][b][r];
+            }
+}
+
+// The same product with the operands staged through LDS: a 32-row block of g and of x (the workgroup's 128 columns of
+// each) arrives as coalesced 16-byte loads, the next block sits in registers while the matrix cores work on the current
+// one, and the MFMA fragments are 4-byte LDS reads.  (k_grad_weight fetches every fragment element with its own 4-byte
+// global load, twice over -- two of the four wavefronts share each operand half: 42-46 us per launch on 37 k x 128 x 128
+// where the products need ~10.)  Needs 16-byte aligned rows and O, I multiples of 4; summation order per output element is
+// that of k_grad_weight (rows in order inside a chunk, chunks added by k_col_final).
+__global__ void __launch_bounds__(256) k_grad_weight_lds(const float *__restrict__ g, int64_t ldg, const float *__restrict__ x,
+                                                         int64_t ldx, int M, int O, int I, int rows,
+                                                         float *__restrict__ partial) {
+    __shared__ float sg[32][128], sx[32][128];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fi = lane & 31, fh = lane >> 5;
+    const int bi_n = (I + 127) / 128;
+    const int ob = (blockIdx.y / bi_n) * 128, ib = (blockIdx.y % bi_n) * 128;
+    const int ow = (wid >> 1) * 64, iw = (wid & 1) * 64;              // this wavefront's 64 x 64 corner of the 128 x 128 block
+    const int r0 = blockIdx.x * rows, r1 = min(r0 + rows, M);
+    f32x16g acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // staging plan: thread t moves float4 number t and t + 256, ... of a 32 x 128 block: row = q / 32, columns 4 (q % 32)
+    float4 pg[4], px[4];
+    auto fetch = [&](int k) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int q = tid + 256 * p, row = k + (q >> 5), c = (q & 31) * 4;
+            const bool live = row < r1;
+            pg[p] = (live && ob + c < O) ? *reinterpret_cast<const float4 *>(g + (int64_t)row * ldg + ob + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            px[p] = (live && ib + c < I) ? *reinterpret_cast<const float4 *>(x + (int64_t)row * ldx + ib + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    fetch(r0);
+    for (int k = r0; k < r1; k += 32) {
+        __syncthreads();                                    // the previous block's fragment reads are done
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int q = tid + 256 * p;
+            *reinterpret_cast<float4 *>(&sg[q >> 5][(q & 31) * 4]) = pg[p];
+            *reinterpret_cast<float4 *>(&sx[q >> 5][(q & 31) * 4]) = px[p];
+        }
+        __syncthreads();
+        if (k + 32 < r1) fetch(k + 32);                     // in flight behind the 64 MFMAs below
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const float a0 = sg[2 * u + fh][ow + fi], a1 = sg[2 * u + fh][ow + 32 + fi];
+            const float b0 = sx[2 * u + fh][iw + fi], b1 = sx[2 * u + fh][iw + 32 + fi];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    float *dst = partial + (int64_t)blockIdx.x * O * I;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = ob + ow + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * fh, i = ib + iw + 32 * b + fi;
                 if (o < O && i < I) dst[(int64_t)o * I + i] = acc[a][b][r];
             }
 }
@@ -316,7 +386,11 @@ extern "C" int blgnn_grad_weight(const float *g, int64_t ldg, const float *x, in
     hipStream_t s = (hipStream_t)stream;
     const int rows = gw_rows(M, O, I);
     const int chunks = (M + rows - 1) / rows;
-    if (chunks > 0)
+    const bool vec = O % 4 == 0 && I % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0 && aligned16(g) && aligned16(x);
+    if (chunks > 0 && vec)
+        hipLaunchKernelGGL(k_grad_weight_lds, dim3(chunks, ((O + 127) / 128) * ((I + 127) / 128)), dim3(256), 0, s, g, ldg, x,
+                           ldx, M, O, I, rows, scratch);
+    else if (chunks > 0)
         hipLaunchKernelGGL(k_grad_weight, dim3(chunks, ((O + 127) / 128) * ((I + 127) / 128)), dim3(256), 0, s, g, ldg, x, ldx,
                            M, O, I, rows, scratch);
     hipLaunchKernelGGL(k_col_final, dim3((O * I + 63) / 64), dim3(256), 0, s, scratch, chunks, O * I, 1.f, dw);

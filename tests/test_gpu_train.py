@@ -532,6 +532,22 @@ def test_grad_weight_and_column_reductions_ragged_shapes(device, M, O, I):
         assert torch.equal(ops.col_reduce(gd, "sum"), ops.col_reduce(gd, "sum"))
 
 
+@pytest.mark.parametrize("M,O,I", [(37001, 128, 128), (1025, 132, 40), (2049, 64, 300), (33, 4, 8), (5000, 256, 128)])
+def test_grad_weight_aligned_operands_take_the_lds_staged_kernel(device, M, O, I):
+    """16-byte aligned rows with O, I multiples of 4 (the layers' own activations): the LDS-staged weight-gradient kernel
+    -- row blocks of 32 with a ragged last block, output blocks cut by O / I, several 128 x 128 output blocks; against
+    fp64 and bit for bit reproducible"""
+    g = torch.Generator().manual_seed(M + O + I + 1)
+    gw, xw = torch.randn(M, O, generator=g), torch.randn(M, I, generator=g)
+    ref = gw.double().t() @ xw.double()
+    gd, xd = gw.to(device), xw.to(device)
+    got = ops.grad_weight(gd, xd)
+    assert max_err(got, ref) < TOL
+    assert torch.equal(ops.grad_weight(gd, xd), got)
+    wide = torch.randn(M, I + 8, generator=g).to(device)                       # aligned column slice of a wider buffer
+    assert max_err(ops.grad_weight(gd, wide[:, 4:4 + I]), gw.double().t() @ wide[:, 4:4 + I].double().cpu()) < TOL
+
+
 def test_train_step_captured_equals_eager(device):
     """blgnn.TrainStep: the training iteration (molecular sweep with gradients -> init_x -> pair batch -> BCE -> backward
     -> SGD step) captured in a HIP graph and replayed on fresh batches follows the same trajectory as the identical
