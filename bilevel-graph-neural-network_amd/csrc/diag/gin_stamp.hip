@@ -9,7 +9,8 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 int main(int argc, char **argv) {
     const int per = argc > 1 ? atoi(argv[1]) : 40;              // atoms per molecule (64: no molecule straddles a 64-row tile)
-    const int n = 498729 / per * per, K = 256, N = 256;
+    const int N = argc > 2 ? atoi(argv[2]) : 256, K = N;        // build with -DGIN_STAMP_N=128 for the d = 128 kernel
+    const int n = (argc > 3 ? atoi(argv[3]) : 498729) / per * per;
     std::vector<int> rp(n + 1), col;
     for (int i = 0; i < n; ++i) {                        // chains of 40 atoms + a few ring closures: ~2.1 edges per atom
         rp[i] = (int)col.size();
@@ -38,7 +39,7 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0); for (int i = 0; i < 10; ++i) run(); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("gin d=256 %d rows: %.1f us per launch\n", n, ms * 100.0);
+    printf("gin d=%d %d rows: %.1f us per launch\n", N, n, ms * 100.0);
     unsigned long long st[16];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(blgnn::g_gin_stamps), sizeof(st));
     const char *names[] = {"entry", "staged (loads landed)", "gathered+split", "hmax atomics (GEMM1 + act done)", "hidden split parked", "GEMM2 + staged", "", "", "stores issued", "GEMM1 done", "GEMM2 done"};

@@ -27,7 +27,10 @@ namespace blgnn {
 
 #ifdef GIN_STAMP
 __device__ unsigned long long g_gin_stamps[16];    // diagnostics: 100 MHz ticks at the phase boundaries of one workgroup
-#define GIN_TICK(i) do { if (N == 256 && blockIdx.x == gridDim.x / 2 + 5 && threadIdx.x == 0) g_gin_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#ifndef GIN_STAMP_N
+#define GIN_STAMP_N 256
+#endif
+#define GIN_TICK(i) do { if (N == GIN_STAMP_N && blockIdx.x == gridDim.x / 2 + 5 && threadIdx.x == 0) g_gin_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define GIN_TICK(i) do { } while (0)
 #endif
@@ -209,6 +212,7 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
     unsigned *hmax = reinterpret_cast<unsigned *>(ainv + XBM);   // [XBM] row maxima of the hidden tile (float bits)
     int *rgraph = reinterpret_cast<int *>(hmax + XBM);           // [XBM] graph of every tile row (fused readout)
     float *rweight = reinterpret_cast<float *>(rgraph + XBM);    // [XBM] readout weight of every tile row
+    int *nb = reinterpret_cast<int *>(rweight + XBM);            // [XBM][4] first four neighbours of every tile row, resolved
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
     const int fi = lane & 31, fh = lane >> 5;
     const int sub = lane / LG, l = lane % LG;
@@ -279,6 +283,23 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
     lds_barrier();
     GIN_TICK(1);
 
+    // neighbour table: slot q of tile row m resolved ONCE by one thread instead of by each of the row's 16-64 lanes in
+    // the gather (the gather phase is vector-instruction bound: ~230 instructions per row pass, a quarter of them this
+    // index arithmetic).  >= 0: tile-local row to add; -1: nothing (unused slot / self loop); <= -2: out-of-tile row -2 - v
+    if (threadIdx.x < XBM * 4) {
+        const int m = threadIdx.x >> 2, q = threadIdx.x & 3;
+        const int row = m0 + m;
+        const int e0 = rp[m], cnt = rp[m + 1] - e0;
+        const int ci = e0 + q - e_lo;
+        int v = -1;
+        if (q < cnt && cols_in_lds && ci < HCOLS) {
+            const int j = cs[ci], jl = j - m0;
+            v = (jl >= 0 && jl < XBM) ? (j != row ? jl : -1) : -2 - j;
+        }
+        nb[threadIdx.x] = v;
+    }
+    lds_barrier();
+
     // ---- (1) gather from LDS (+ out-of-tile rows from L2, FB passes per round trip), scale, split, park --------
     constexpr int FBMAX = XBM == 64 ? 4 : 2;       // 16 VGPRs per pass in flight
     constexpr int FB = PASSES < FBMAX ? PASSES : FBMAX;
@@ -295,17 +316,13 @@ __global__ void __launch_bounds__(N * 2, (XBM == 64 || N == 256) ? 2 : 4) k_gin_
             accv[pp] = *reinterpret_cast<const float4 *>(Xs + m * A.K + lo4);
             accv[pp].x *= A.self_coef; accv[pp].y *= A.self_coef;
             accv[pp].z *= A.self_coef; accv[pp].w *= A.self_coef;
+            const int4 nv = *reinterpret_cast<const int4 *>(nb + 4 * m);
+            const int nq[4] = {nv.x, nv.y, nv.z, nv.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                int ci = e0 + q - e_lo;
-                ci = (q < cnt && ci < HCOLS) ? ci : 0;
-                const int c = cs[ci];
-                const int j = (q < cnt && cols_in_lds) ? c : row;
-                const int jl = j - m0;
-                const bool in_tile = jl >= 0 && jl < XBM;
-                far[pp][q] = (in_tile || !ok) ? -1 : j;
-                const bool use = in_tile && j != row;
-                const float4 u = *reinterpret_cast<const float4 *>(Xs + (use ? jl : m) * A.K + lo4);
+                const bool use = nq[q] >= 0;
+                far[pp][q] = (nq[q] <= -2 && ok) ? -2 - nq[q] : -1;
+                const float4 u = *reinterpret_cast<const float4 *>(Xs + (use ? nq[q] : m) * A.K + lo4);
                 f4_fma(accv[pp], use ? 1.f : 0.f, u);
             }
         }
@@ -519,7 +536,8 @@ static size_t h3_lds_bytes(int K, int Kp, int XBM, int N = 128) {
     if ((size_t)XBM * (N + 4) * 4 > r0) r0 = (size_t)XBM * (N + 4) * 4;
     size_t r1 = (size_t)XBM * K * 4;
     if ((size_t)2 * XBM * (N * 2 + 16) > r1) r1 = (size_t)2 * XBM * (N * 2 + 16);
-    return r0 + r1 + sizeof(int) * (XBM + 4 + HCOLS) + sizeof(float) * 2 * XBM + (sizeof(int) + sizeof(float)) * XBM;
+    return r0 + r1 + sizeof(int) * (XBM + 4 + HCOLS) + sizeof(float) * 2 * XBM + (sizeof(int) + sizeof(float)) * XBM +
+           sizeof(int) * 4 * XBM;
 }
 
 template <int LG, int ACT, int XBM, bool CODES, int N, bool POOL>
