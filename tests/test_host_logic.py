@@ -100,6 +100,47 @@ def test_negative_sampling_rules():
     assert bd.pair_list[20].true_label == 0 and bd.pair_list[3].true_label == 1
 
 
+def _negatives_one_candidate_at_a_time(ds, pos_pairs, sampled, rng, enforce=True):
+    """the acceptance loop of src/batch.py:75-98 as the reference writes it (one candidate per python iteration): the
+    whole-array sampler of blgnn/batch.py must pick the same negatives from the same random draws"""
+    gs_map = ds.gs_map
+    want = len(pos_pairs)
+    n = len(sampled)
+    want = int(min(want, n * (n - 1) // 2 - len(pos_pairs)))
+    N = np.int64(ds.num_graphs())
+    rows = np.vectorize(gs_map.get)
+    bp = rows(pos_pairs)
+    pos = np.union1d(ds.positive_pair_keys(), np.minimum(bp[:, 0], bp[:, 1]) * N + np.maximum(bp[:, 0], bp[:, 1]))
+    chosen, seen, cursor = [], set(), 0
+    while len(chosen) < want:
+        m = max(2 * (want - len(chosen)), 16)
+        a = sampled[(cursor + np.arange(m)) % n]
+        cursor += m
+        b = rng.choice(sampled, size=m)
+        ra, rb = rows(a), rows(b)
+        key = np.minimum(ra, rb) * N + np.maximum(ra, rb)
+        ok = (a != b) & ~np.isin(key, pos)
+        for x, y, k, good in zip(a, b, key, ok):
+            if good and int(k) not in seen:
+                seen.add(int(k))
+                chosen.append((int(x), int(y)))
+                if len(chosen) == want:
+                    break
+    return np.asarray(chosen)
+
+
+@pytest.mark.parametrize("seed,batch", [(1, 16), (2, 64), (3, 200)])
+def test_vectorised_negative_sampler_picks_what_the_candidate_loop_picks(seed, batch):
+    ds = blgnn.make_synthetic(60, 400, seed=10 + seed, device="cpu")
+    set_flags(blgnn.make_flags("lower_level_gnn", device="cpu"))
+    pos = ds.pair_gids[np.random.default_rng(seed).choice(len(ds.pair_gids), size=batch, replace=False)]
+    sampled = np.unique(pos)
+    bd = BatchData(pos, ds, sampled_gids=sampled, is_train=True, rng=np.random.default_rng(100 + seed))
+    ref = _negatives_one_candidate_at_a_time(ds, pos, sampled, np.random.default_rng(100 + seed))
+    assert np.array_equal(bd.negative_pair_gids, ref)
+    assert len(bd.pair_list) == len(bd.batch_gids) and bd.pair_list[len(pos)].true_label == 0
+
+
 def test_random_sampler_covers_every_pair_once_per_epoch():
     ds = blgnn.make_synthetic(15, 50, seed=2, device="cpu")
     data = blgnn.TrainData(ds, device="cpu")
