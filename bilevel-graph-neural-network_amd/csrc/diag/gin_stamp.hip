@@ -3,7 +3,10 @@
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
+#include <algorithm>
 #define GIN_STAMP
+#define GIN_OLD256          // also build round 3's one-workgroup-per-CU kernel (selected by the environment variable GIN_OLD256)
 #include "../gin_h3.hip"
 #include "../runtime.hip"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -34,17 +37,34 @@ int main(int argc, char **argv) {
     blgnn_pack_weight_h3(w, N, K, N, w1p, nullptr); blgnn_pack_weight_h3(w, N, N, N, w2p, nullptr);
     auto run = [&]() { return blgnn_gin_layer_h3(drp, dcol, (int64_t)col.size(), x, K, n, K, w1p, b, w2p, b, N, 0.1f, 1, nullptr, nullptr, nullptr, y, N,
                                                 nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, nullptr); };
-    for (int i = 0; i < 3; ++i) if (run()) { printf("rc %s\n", blgnn_last_error()); return 1; }
-    CK(hipDeviceSynchronize());
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0); for (int i = 0; i < 10; ++i) run(); hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("gin d=%d %d rows: %.1f us per launch\n", N, n, ms * 100.0);
-    unsigned long long st[16];
-    hipMemcpyFromSymbol(st, HIP_SYMBOL(blgnn::g_gin_stamps), sizeof(st));
-    const char *names[] = {"entry", "staged (loads landed)", "gathered+split", "hmax atomics (GEMM1 + act done)", "hidden split parked", "GEMM2 + staged", "", "", "stores issued", "GEMM1 done", "GEMM2 done"};
-    const int order[] = {0, 1, 2, 9, 3, 4, 10, 5, 8};
-    for (int k = 1; k < 9; ++k)
-        printf("  %-34s +%.2f us (at %.2f)\n", names[order[k]], (double)(st[order[k]] - st[order[k - 1]]) / 100.0, (double)(st[order[k]] - st[0]) / 100.0);
+    std::vector<float> y_new((size_t)n * N), y_old((size_t)n * N);
+    for (int variant = 0; variant < (N == 256 ? 2 : 1); ++variant) {
+        if (variant) setenv("GIN_OLD256", "1", 1); else unsetenv("GIN_OLD256");
+        CK(hipMemset(y, 0, (size_t)n * N * 4));
+        for (int i = 0; i < 3; ++i) if (run()) { printf("rc %s\n", blgnn_last_error()); return 1; }
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy((variant ? y_old : y_new).data(), y, (size_t)n * N * 4, hipMemcpyDeviceToHost));
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0); for (int i = 0; i < 20; ++i) run(); hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("gin d=%d %d rows (%s): %.1f us per launch\n", N, n, variant ? "one 512-thread workgroup per CU, round 3" : (N == 256 ? "two 256-thread workgroups per CU" : "d = 128 kernel"), ms * 50.0);
+        unsigned long long st[16];
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(blgnn::g_gin_stamps), sizeof(st));
+        if (variant || N != 256) {
+            const char *names[] = {"entry", "staged (loads landed)", "gathered+split", "hmax atomics (GEMM1 + act done)", "hidden split parked", "GEMM2 + staged", "", "", "stores issued", "GEMM1 done", "GEMM2 done"};
+            const int order[] = {0, 1, 2, 9, 3, 4, 10, 5, 8};
+            for (int k = 1; k < 9; ++k)
+                printf("  %-34s +%.2f us (at %.2f)\n", names[order[k]], (double)(st[order[k]] - st[order[k - 1]]) / 100.0, (double)(st[order[k]] - st[0]) / 100.0);
+        } else {
+            const char *names[] = {"entry", "staged (loads landed)", "gathered into registers", "pieces parked", "GEMM1 done", "act + row maxima", "hidden pieces parked", "GEMM2 done", "output tile staged", "stores issued"};
+            for (int k = 1; k < 10; ++k)
+                printf("  %-34s +%.2f us (at %.2f)\n", names[k], (double)(st[k] - st[k - 1]) / 100.0, (double)(st[k] - st[0]) / 100.0);
+        }
+    }
+    if (N == 256) {
+        size_t bad = 0; double worst = 0;
+        for (size_t i = 0; i < y_new.size(); ++i) if (y_new[i] != y_old[i]) { ++bad; worst = std::max(worst, (double)fabsf(y_new[i] - y_old[i])); }
+        printf("new vs round-3 kernel: %zu of %zu values differ (max |d| %.3g)\n", bad, y_new.size(), worst);
+    }
     return 0;
 }

@@ -583,6 +583,7 @@ static int h3_codes_pick_act(const GinH3Args &A, hipStream_t s) {
     }
 }
 
+#ifdef GIN_OLD256       // diagnostics only (csrc/diag/gin_stamp.hip): round 3's one-workgroup-per-CU kernel
 // N = 256: 64-row tiles, 512 threads
 template <int LG>
 static int h3w_pick_act(const GinH3Args &A, hipStream_t s) {
@@ -594,6 +595,7 @@ static int h3w_pick_act(const GinH3Args &A, hipStream_t s) {
         default:                return launch_h3_rows<LG, BLGNN_ACT_IDENTITY, 64, false, 256>(A, s);
     }
 }
+#endif
 
 template <int LG>
 static int h3_pick_act(const GinH3Args &A, hipStream_t s) {
@@ -607,6 +609,9 @@ static int h3_pick_act(const GinH3Args &A, hipStream_t s) {
 }
 
 }  // namespace blgnn
+
+#include "gin_h3q.hpp"       // N = 256: 64-row tiles of 256-thread workgroups, two per CU
+
 
 using namespace blgnn;
 
@@ -666,9 +671,16 @@ extern "C" int blgnn_gin_layer_h3(const int32_t *rowptr, const int32_t *col, int
     hipStream_t s = (hipStream_t)stream;
     const int k4 = K / 4;
     if (N == 256) {
-        if (k4 <= 16) return h3w_pick_act<16>(A, s);
-        if (k4 <= 32) return h3w_pick_act<32>(A, s);
-        return h3w_pick_act<64>(A, s);
+#ifdef GIN_OLD256
+        if (getenv("GIN_OLD256")) {
+            if (k4 <= 16) return h3w_pick_act<16>(A, s);
+            if (k4 <= 32) return h3w_pick_act<32>(A, s);
+            return h3w_pick_act<64>(A, s);
+        }
+#endif
+        if (k4 <= 16) return h3q_pick_act<16, 1>(A, s);
+        if (k4 <= 32) return h3q_pick_act<32, 1>(A, s);
+        return h3q_pick_act<32, 2>(A, s);
     }
     if (k4 <= 16) return h3_pick_act<16>(A, s);
     return h3_pick_act<32>(A, s);
