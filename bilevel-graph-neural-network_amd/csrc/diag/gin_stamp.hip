@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <map>
 #include <algorithm>
 #define GIN_STAMP
 #define GIN_OLD256          // also build round 3's one-workgroup-per-CU kernel (selected by the environment variable GIN_OLD256)
@@ -60,6 +61,48 @@ int main(int argc, char **argv) {
             for (int k = 1; k < 10; ++k)
                 printf("  %-34s +%.2f us (at %.2f)\n", names[k], (double)(st[k] - st[k - 1]) / 100.0, (double)(st[k] - st[0]) / 100.0);
         }
+    }
+    if (N == 256 && getenv("GIN_TL")) {
+        // per-CU timelines of the last launch of the new kernel?  No: the table holds the LAST launch, which was the round-3
+        // kernel's unless GIN_TL_NEW re-runs the new one here
+        unsetenv("GIN_OLD256");
+        run(); CK(hipDeviceSynchronize());
+        static unsigned long long tl[8192][12];
+        CK(hipMemcpyFromSymbol(tl, HIP_SYMBOL(blgnn::g_gin_tl), sizeof(tl)));
+        const int nb = std::min(8192, (n + 63) / 64);
+        // key = (xcc, se, cu); HW_ID (gfx9): wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13
+        std::map<unsigned, std::vector<int>> by_cu;
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < nb; ++b) { t0 = std::min(t0, tl[b][0]); const unsigned hw = (unsigned)tl[b][11], xcc = (unsigned)(tl[b][11] >> 32) & 15u;
+            by_cu[(xcc << 16) | (hw & 0xff00u)].push_back(b); }
+        printf("%zu distinct (xcc, se, sh, cu) keys for %d workgroups\n", by_cu.size(), nb);
+        // GEMM intervals: [3,4] and [6,7]; fraction of a workgroup's GEMM time during which another workgroup of its CU is in a GEMM too
+        double gemm_total = 0, gemm_shared = 0, span = 0; int shown = 0;
+        for (auto &kv : by_cu) {
+            auto &v = kv.second;
+            std::sort(v.begin(), v.end(), [&](int a, int b) { return tl[a][0] < tl[b][0]; });
+            for (size_t i = 0; i < v.size(); ++i) for (int g = 0; g < 2; ++g) {
+                const unsigned long long a0 = tl[v[i]][3 + 3 * g], a1 = tl[v[i]][4 + 3 * g];
+                gemm_total += (double)(a1 - a0);
+                for (size_t j = 0; j < v.size(); ++j) if (j != i) for (int h = 0; h < 2; ++h) {
+                    const unsigned long long b0 = tl[v[j]][3 + 3 * h], b1 = tl[v[j]][4 + 3 * h];
+                    const unsigned long long lo = std::max(a0, b0), hi = std::min(a1, b1);
+                    if (hi > lo) gemm_shared += (double)(hi - lo);
+                }
+            }
+            if (shown < 2) {
+                ++shown;
+                printf("CU key %06x: %zu workgroups; first ten: block(slot) start..end [gemm1][gemm2] in us\n", kv.first, v.size());
+                for (size_t i = 0; i < std::min<size_t>(10, v.size()); ++i) {
+                    const int b = v[i];
+                    printf("   %5d (w%llu simd%llu) %7.2f..%7.2f  [%7.2f..%7.2f] [%7.2f..%7.2f]\n", b, tl[b][11] & 15, (tl[b][11] >> 4) & 3, (tl[b][0] - t0) / 100.0, (tl[b][9] - t0) / 100.0,
+                           (tl[b][3] - t0) / 100.0, (tl[b][4] - t0) / 100.0, (tl[b][6] - t0) / 100.0, (tl[b][7] - t0) / 100.0);
+                }
+            }
+            span = std::max(span, (double)(tl[v.back()][9] - t0));
+        }
+        printf("GEMM time per workgroup-tile %.2f us; %.0f %% of it beside another GEMM of the same CU; last store at %.1f us\n",
+               gemm_total / nb / 100.0, 100.0 * gemm_shared / gemm_total, span / 100.0);
     }
     if (N == 256) {
         size_t bad = 0; double worst = 0;

@@ -30,7 +30,11 @@ __device__ unsigned long long g_gin_stamps[16];    // diagnostics: 100 MHz ticks
 #ifndef GIN_STAMP_N
 #define GIN_STAMP_N 256
 #endif
-#define GIN_TICK(i) do { if (N == GIN_STAMP_N && blockIdx.x == gridDim.x / 2 + 5 && threadIdx.x == 0) g_gin_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long g_gin_tl[8192][12];  // the same for every workgroup of the N = 256 kernel; [11] = HW_ID | XCC_ID << 32
+#define GIN_TICK(i) do { if (N == GIN_STAMP_N && threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
+        if (blockIdx.x == gridDim.x / 2 + 5) g_gin_stamps[i] = t_; \
+        if (N == 256 && blockIdx.x < 8192) { g_gin_tl[blockIdx.x][i] = t_; \
+            if ((i) == 0) g_gin_tl[blockIdx.x][11] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } } } while (0)
 #else
 #define GIN_TICK(i) do { } while (0)
 #endif
@@ -678,9 +682,7 @@ extern "C" int blgnn_gin_layer_h3(const int32_t *rowptr, const int32_t *col, int
             return h3w_pick_act<64>(A, s);
         }
 #endif
-        if (k4 <= 16) return h3q_pick_act<16, 1>(A, s);
-        if (k4 <= 32) return h3q_pick_act<32, 1>(A, s);
-        return h3q_pick_act<32, 2>(A, s);
+        return h3q_dispatch(A, s);
     }
     if (k4 <= 16) return h3_pick_act<16>(A, s);
     return h3_pick_act<32>(A, s);
