@@ -231,6 +231,8 @@ class _BatchNormTrain(torch.autograd.Function):
                 # rstd and torch's running-statistics update (momentum form, unbiased variance) in one launch
                 rm, rv, mom = running
                 rstd = ops.bn_finalize(mean, var, eps, mom, count / max(count - 1.0, 1.0), rm, rv)
+                # the kernel wrote rm / rv through raw pointers: the eval-BN fold is cached on their versions
+                torch.autograd.graph.increment_version((rm, rv))
         else:
             # two-pass over the union of the ranks' rows: global sum -> mean, global centred squares -> variance
             buf = torch.empty(N + 1, dtype=torch.float32, device=x.device)

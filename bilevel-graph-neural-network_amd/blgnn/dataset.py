@@ -60,14 +60,16 @@ class BiGNNDataset(object):
         as the dict lookup of the reference does."""
         gids = np.asarray(gids, dtype=np.int64)
         lut = getattr(self, "_gid_lut", None)
-        if lut is None or getattr(self, "_gid_lut_len", -1) != len(self.gs_map):
+        # (keyed on the map OBJECT and its size: assigning a new gs_map rebuilds the table; code that remaps entries of
+        #  the same dict in place calls ``invalidate_gid_table()``)
+        if lut is None or getattr(self, "_gid_lut_key", None) != (id(self.gs_map), len(self.gs_map)):
             keys = np.fromiter(self.gs_map.keys(), dtype=np.int64, count=len(self.gs_map))
             if len(keys) and keys.min() >= 0 and keys.max() < 16 * len(keys) + 1024:
                 lut = np.full(int(keys.max()) + 1, -1, dtype=np.int64)
                 lut[keys] = np.fromiter(self.gs_map.values(), dtype=np.int64, count=len(self.gs_map))
             else:
                 lut = False
-            self._gid_lut, self._gid_lut_len = lut, len(self.gs_map)
+            self._gid_lut, self._gid_lut_key = lut, (id(self.gs_map), len(self.gs_map))
         if lut is False:
             return np.vectorize(self.gs_map.__getitem__, otypes=[np.int64])(gids)
         if gids.size and (gids.min() < 0 or gids.max() >= lut.shape[0]):
@@ -76,6 +78,10 @@ class BiGNNDataset(object):
         if (rows < 0).any():
             raise KeyError(int(gids[rows < 0].reshape(-1)[0]))
         return rows
+
+    def invalidate_gid_table(self):
+        """call after changing entries of ``gs_map`` in place (a re-split / fold change that reassigns rows)"""
+        self._gid_lut = None
 
     def num_graphs(self):
         return len(self.molecules)

@@ -37,6 +37,9 @@ class GraphData(object):
         self.x, self.edge_index, self.edge_attr, self.batch = x, edge_index, edge_attr, batch
         self._num_nodes = num_nodes
         self.num_graphs = num_graphs
+        # True when the builder of this object guarantees a symmetric edge set (to_undirected / a checked MoleculeStore):
+        # the CSR then skips its device-side symmetry check (ops.CSR.require_symmetric)
+        self.symmetric_by_construction = False
         self._csr = None
         self._seg = None
         self._batch32 = None
@@ -62,6 +65,8 @@ class GraphData(object):
     def csr(self, symmetric=True):
         if self._csr is None:
             self._csr = ops.csr_from_edge_index(self.edge_index, self.num_nodes, symmetric)
+            if symmetric and self.symmetric_by_construction:
+                self._csr._symmetric = True
         return self._csr
 
     def segments(self):
@@ -96,6 +101,7 @@ def merge_from_data_list(graphs_in_batch, unique_graphs=True):
     batch = torch.repeat_interleave(
         torch.arange(len(data_list), device=dev), torch.as_tensor(sizes, device=dev))
     merged = GraphData(x=x, edge_index=ei, batch=batch, num_graphs=len(data_list))
+    merged.symmetric_by_construction = all(getattr(d, "symmetric_by_construction", False) for d in data_list)
     merged._seg = torch.as_tensor(node_off, dtype=torch.int32, device=dev)
     ind_list = [(int(node_off[i]), int(node_off[i + 1])) for i in range(len(data_list))]
     edge_ind_list = [(int(edge_off[i]), int(edge_off[i + 1])) for i in range(len(data_list))]
@@ -127,7 +133,15 @@ class MoleculeStore(object):
         self.esizes = np.diff(self.edge_ptr)
         self.device = torch.device(device)
         self.x = torch.as_tensor(x_all, dtype=torch.float32).to(self.device)
-        self.edge_local = torch.as_tensor(edge_local, dtype=torch.int64).to(self.device)
+        el = np.asarray(edge_local.cpu() if isinstance(edge_local, torch.Tensor) else edge_local, dtype=np.int64).reshape(2, -1)
+        # the contract above, checked ONCE per store on the host: every batch merged from it is symmetric by construction
+        # (the backward kernels reuse the forward CSR as its transpose; ops.CSR.require_symmetric)
+        mol = np.repeat(np.arange(len(self.esizes), dtype=np.int64), self.esizes)
+        width = int(self.sizes.max()) + 1 if len(self.sizes) else 1
+        fwd = np.sort((mol * width + el[0]) * width + el[1])
+        bwd = np.sort((mol * width + el[1]) * width + el[0])
+        self.symmetric = bool(fwd.shape == bwd.shape and (fwd == bwd).all())
+        self.edge_local = torch.as_tensor(el).to(self.device)
         self.num_node_feat = int(self.x.shape[1])
         self.codes, self.code_offsets = None, None
         if codes is not None and cards is not None and len(cards) <= 8:
@@ -152,7 +166,9 @@ class MoleculeStore(object):
         p = self.gid_to_pos[gid]
         a, b = int(self.node_ptr[p]), int(self.node_ptr[p + 1])
         ea, eb = int(self.edge_ptr[p]), int(self.edge_ptr[p + 1])
-        return GraphData(x=self.x[a:b], edge_index=self.edge_local[:, ea:eb])
+        g = GraphData(x=self.x[a:b], edge_index=self.edge_local[:, ea:eb])
+        g.symmetric_by_construction = self.symmetric
+        return g
 
     def merge(self, gid_list, unique_graphs=True):
         """Vectorised equivalent of ``merge_from_data_list`` for molecules of this
@@ -176,6 +192,7 @@ class MoleculeStore(object):
         ei = self.edge_local.index_select(1, src_edge_t) + torch.as_tensor(shift, device=dev)
         batch = torch.as_tensor(g_of_node, device=dev)
         merged = GraphData(x=x, edge_index=ei, batch=batch, num_graphs=G)
+        merged.symmetric_by_construction = self.symmetric
         merged._seg = torch.as_tensor(node_off, dtype=torch.int32, device=dev)
         if self.codes is not None:
             merged.codes = self.codes.index_select(0, src_node_t)
@@ -216,5 +233,6 @@ class InteractionGraph(object):
             ei = to_undirected_host(self.edges, self.num_nodes)
             self._data = GraphData(edge_index=torch.as_tensor(ei).to(device),
                                    num_nodes=self.num_nodes)
+            self._data.symmetric_by_construction = True          # to_undirected_host
         self._data.x = self.init_x
         return self._data

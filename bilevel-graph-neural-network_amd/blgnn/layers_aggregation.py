@@ -183,6 +183,10 @@ class NodeAggregation(NodeAggregationPairs):
                 base = graph.init_x if isinstance(graph.init_x, torch.Tensor) and \
                     graph.init_x.shape[1] == out.shape[1] else \
                     torch.zeros((n_all, out.shape[1]), dtype=torch.float32, device=out.device)
+                if rng is not None and rng[0] == 0 and base.requires_grad:
+                    # the first chunk of a sweep driven WITHOUT get_initial_embd (a loop calling model(b) per chunk):
+                    # start from values, not from the previous iteration's (freed) autograd graph
+                    base = base.detach()
                 graph.init_x = base.index_copy(0, rows.long(), out)     # row placement: data movement only
             return out
         # layers_aggregation.py:68-74: init_x[gs_map[gid]] = out[ind]

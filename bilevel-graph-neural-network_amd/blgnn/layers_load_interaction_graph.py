@@ -30,6 +30,7 @@ class LoadInteractionGraph(nn.Module):
                 if data is None:
                     data = GraphData(edge_index=create_edge_index(v)[0],
                                      num_nodes=v.number_of_nodes())
+                    data.symmetric_by_construction = True        # create_edge_index: to_undirected
                     v._blgnn_edge_data = data
                 edges[k] = data
         return batch_data.merge_higher_level['merge'].x

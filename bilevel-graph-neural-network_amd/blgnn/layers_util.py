@@ -207,6 +207,7 @@ def convert_nx_to_pyg_graph(g):
     if cache is None or cache[0] != g.number_of_edges():
         ei, _ = create_edge_index(g)
         cache = (g.number_of_edges(), GraphData(edge_index=ei, num_nodes=g.number_of_nodes()))
+        cache[1].symmetric_by_construction = True                # create_edge_index: to_undirected
         g._blgnn_data = cache
     data = cache[1]
     x = g.init_x

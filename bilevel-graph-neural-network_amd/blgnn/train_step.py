@@ -47,6 +47,8 @@ class TrainStep(object):
         self.template._pair_row_ids = (self.ids[0], self.ids[1])
         self.template.true_labels = lambda: self.labels
         self.scorer = [l for l in model.layers if hasattr(l, "pair_row_ids")][-1]
+        self._copied = torch.cuda.Event()
+        self._versioned = None
         self.graph = None
         self.loss = None
         self.stream = torch.cuda.Stream(device=dev) if capture else None
@@ -81,10 +83,30 @@ class TrainStep(object):
             raise ValueError("blgnn: TrainStep was built for %d pairs per batch, got %d"
                              % (self.num_pairs, len(batch.batch_gids)))
         host = self.scorer.pair_row_ids(batch)
+        self._copied.synchronize()               # the previous batch's H2D copies have read the pinned staging buffers
         self._host_ids.copy_(torch.from_numpy(np.ascontiguousarray(host.T)))
         self._host_labels.copy_(torch.from_numpy(np.asarray(batch._labels, dtype=np.float32)))
         self.ids.copy_(self._host_ids, non_blocking=True)
         self.labels.copy_(self._host_labels, non_blocking=True)
+        self._copied.record(torch.cuda.current_stream(self.device))
+
+    def _bump_versions(self):
+        """A replay writes the parameters (optimizer step) and the BatchNorm statistics through the captured kernels:
+        ``Tensor._version`` does not move, and every derived-tensor cache of the package (transposed / packed weights, the
+        eval-BN fold, the GMN composed weights, the engine's capture stamp) is keyed on (data_ptr, _version).  Host-side
+        counter bumps, no launch: an eval forward between two replays (src/train.py:152 validates every
+        ``iters_per_validation`` iterations) then re-derives from the weights the replay left."""
+        if self._versioned is None:
+            seen, ts = set(), []
+            for group in self.opt.param_groups:
+                for p in group["params"]:
+                    if id(p) not in seen:
+                        seen.add(id(p)); ts.append(p)
+            for t in list(self.model.parameters()) + list(self.model.buffers()):
+                if id(t) not in seen:
+                    seen.add(id(t)); ts.append(t)
+            self._versioned = ts
+        torch.autograd.graph.increment_version(self._versioned)
 
     def step(self, batch):
         """Train on ``batch`` (same number of pairs as the first one).  -> the loss (a device scalar; with capture it is a
@@ -98,6 +120,7 @@ class TrainStep(object):
             self.stream.synchronize()
             self._fill(batch)
             self.graph.replay()
+        self._bump_versions()
         # whoever reads the loss (or the parameters) on the caller's stream reads them behind this replay
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return self.loss
