@@ -34,6 +34,12 @@ def pytest_sessionfinish(session, exitstatus):
             summary[test] = {"comparisons": len(rows), "max_abs": max(r["abs"] for r in rows),
                              "max_scaled": max(r["scaled"] for r in rows),
                              "max_ref_magnitude": max(r["ref_max"] for r in rows)}
+            c32 = [r for r in rows if "cpu32_scaled" in r]
+            if c32:                                          # helpers.compare3: the fp32 CPU oracle's own error beside the GPU's
+                summary[test].update({"cpu32_max_abs": max(r["cpu32_abs"] for r in c32),
+                                      "cpu32_max_scaled": max(r["cpu32_scaled"] for r in c32),
+                                      "gpu_max_scaled_where_cpu32_known": max(r["scaled"] for r in c32),
+                                      "worst_gpu_over_cpu32": max(r["scaled"] / max(r["cpu32_scaled"], 1e-12) for r in c32)})
         out = {"bar": helpers.TOL, "worst_abs": max(v["max_abs"] for v in summary.values()),
                "worst_scaled": max(v["max_scaled"] for v in summary.values()), "tests": summary}
         d = os.path.join(ROOT, "gpurun_out")

@@ -51,6 +51,25 @@ def max_err(got, ref):
     return a / max(1.0, rm)
 
 
+def compare3(got, ref64, cpu32):
+    """One comparison with the fp32 CPU oracle's own error beside the GPU's: ``got`` (GPU) and ``cpu32`` (the oracle
+    evaluated in fp32 on the CPU -- the arithmetic the reference itself runs) against ``ref64`` (the oracle in fp64).
+    -> (gpu_scaled, cpu32_scaled); both are recorded in the parity log (keys ``cpu32_abs`` / ``cpu32_scaled``)."""
+    got = got.detach().cpu().double()
+    ref = ref64.detach().cpu().double()
+    c32 = cpu32.detach().cpu().double()
+    if not ref.numel():
+        return 0.0, 0.0
+    rm = float(ref.abs().max())
+    a = float((got - ref).abs().max())
+    c = float((c32 - ref).abs().max())
+    _log(a, a / max(1.0, rm), rm, int(ref.numel()))
+    import os
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    ERROR_LOG[test][-1].update({"cpu32_abs": c, "cpu32_scaled": c / max(1.0, rm)})
+    return a / max(1.0, rm), c / max(1.0, rm)
+
+
 def layer_specs(flags):
     return [getattr(flags, "layer_%d" % i) for i in range(1, flags.layer_num + 1)]
 
