@@ -248,7 +248,7 @@ def perturb_bn(model, seed):
 def pmc_traffic(tag):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
     (profiles/summarize_pmc.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction), or None."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.json" % (rnd, tag))))[
                 "hbm_bytes_per_launch"]
@@ -424,6 +424,19 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
     ops.gin_layer_x6 = timer.wrap("bf16x6", saved[1], work_split, lambda *a, **kw: True)
     ops.gin_layer_h3 = timer.wrap("f16x3", saved[2], work_split, lambda *a, **kw: True)
     saved_stack = ops.gin_stack
+    # the interaction-level gather (blgnn_gat_aggregate -> k_gather_wide on these degrees): bytes it gathers per launch =
+    # one d-wide row per directed edge and self loop of the rows it computes
+    gtimer = KernelTimer()
+    saved_agg = ops.gat_aggregate
+
+    def agg_work(csr, h, sc, stats, bias, *a, **kw):
+        rows = kw.get("rows", a[8] if len(a) > 8 else None)
+        n, dd = h.shape
+        frac = 1.0 if rows is None else float(rows.numel()) / max(n, 1)
+        gathered = 4.0 * dd * (csr.nnz + n) * frac
+        alg = 4.0 * dd * 2 * n + 4.0 * (csr.nnz + n) + 4.0 * (n + 1) + 16.0 * n          # GAT interaction layer
+        return (0.0, alg, gathered)
+    ops.gat_aggregate = gtimer.wrap("gat_aggregate", saved_agg, agg_work, lambda *a, **kw: True)
 
     def work_stack(csr, x0, tile_row, tile_mol, seg, layers, *a, **kw):
         # the one-launch lower level: L x the per-layer algorithmic work (SURVEY 8d defines the bytes per
@@ -470,7 +483,7 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
         # execution, not host launch latency.
         roofline = None
         if want_roofline:                       # every rank: eager steps contain the all-gather
-            timer.enabled = rank == 0
+            timer.enabled = gtimer.enabled = rank == 0
             blk = torch.empty(4096, 8192, device=device)
             blk_w = torch.empty(8192, 8192, device=device)
             for i in range(min(steps, 20)):
@@ -478,10 +491,11 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
                     torch.mm(blk, blk_w)
                 engine.eager_step(fresh[i % pool])
             torch.cuda.synchronize()
-            timer.enabled = False
+            timer.enabled = gtimer.enabled = False
     finally:
         ops.gin_layer, ops.gin_layer_x6, ops.gin_layer_h3 = saved
         ops.gin_stack = saved_stack
+        ops.gat_aggregate = saved_agg
     pairs_per_step = batch * world
     res = {"value": pairs_per_step / (elapsed / steps), "ms_per_step": 1e3 * elapsed / steps,
            "timed_blocks": len(blocks), "ms_per_step_min": 1e3 * min(blocks) / steps,
@@ -520,6 +534,19 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
         if sel:
             res["roofline"] = roofline_of(kname, [ms[i] for i in sel], [work[i] for i in sel], mult, peak,
                                           pmc_traffic(tag + ("_cfg%d" % cfg_id if cfg_id != 1 else "")))
+    if want_roofline and rank == 0:
+        gms, gwork, _ = gtimer.result()
+        if gms:
+            tot = sum(gms) * 1e-3
+            res["interaction_gather"] = {
+                "kernel": "k_gather_wide (blgnn_gat_aggregate: per-source softmax weights + weighted neighbour-row sum of the "
+                          "interaction-level GATConv, one workgroup per target row)",
+                "launches": len(gms), "avg_us": 1e3 * sum(gms) / len(gms),
+                "gathered_GBps": sum(w[2] for w in gwork) / tot / 1e9,
+                "alg_hbm_GBps": sum(w[1] for w in gwork) / tot / 1e9,
+                "alg_hbm_frac": sum(w[1] for w in gwork) / tot / 1e9 / PEAK_HBM_GBPS,
+                "note": "the transformed table (N x d fp32) of the interaction graph is Infinity-Cache resident; the gathered "
+                        "rate is what the micro-architecture guide's 7.4-8.6 TB/s for cache-resident row gathers compares with"}
     engine.close()
     res["_cpu"] = lambda seconds: cpu_baseline_bilevel(ds, flags, model, lower_batch, template, batch, seconds)
     return res
@@ -691,6 +718,51 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
                 other_ms = 1e3 * run_block() / steps
             finally:
                 live.gmn_shared_prefix, live.gmn_pooled_tail = keep
+        # the host side of a batch (src/batch.py:105-144 + src/merged_graph.py: what the reference's evaluate loop does per
+        # batch): the headline cycles through pre-built batches; here a FRESH pair batch is built for every step -- merge
+        # of the molecule slices, CSR, segment offsets, distinct-molecule row map -- on a side stream while the previous
+        # step runs, and the step's forward waits for it
+        build_ms = incl_ms = None
+        if not args.no_extra:
+            side = torch.cuda.Stream(device=device)
+
+            def build():
+                with torch.cuda.stream(side):
+                    b = BatchData(ds.pair_gids[rng.choice(len(ds.pair_gids), size=batch, replace=False)], ds,
+                                  is_train=False, unique_graphs=False)
+                    b.merge_data['merge'].csr()
+                    b.merge_data['merge'].segments()
+                    sm = b.shared_molecules()
+                    if sm is not None:
+                        sm.graph.csr()
+                return b
+
+            def forward_on(b):
+                model.acts = [b.merge_data['merge'].x]
+                with torch.no_grad():
+                    for layer in layers:
+                        model.acts.append(layer(model.acts[-1], b, model))
+                return model.acts[-1]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                nxt = build()
+                side.synchronize()
+            build_ms = 1e3 * (time.perf_counter() - t0) / 3
+            for _ in range(2):                                       # warm the allocator pools of the rotating batches
+                torch.cuda.current_stream().wait_stream(side)
+                forward_on(nxt)
+                nxt = build()
+            torch.cuda.synchronize()
+            D.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                torch.cuda.current_stream().wait_stream(side)
+                cur = nxt
+                forward_on(cur)                                      # enqueue the step ...
+                nxt = build()                                        # ... and build the next batch under it
+            torch.cuda.synchronize()
+            incl_ms = 1e3 * D.max(time.perf_counter() - t0) / steps
         if want_roofline and rank == 0:
             timer.enabled = True
             for i in range(min(steps, 8)):
@@ -726,6 +798,11 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
                  "readout to fp32 rounding: tests/test_gpu_sp.py"} if pooled_active else
         {"on": False, "why": "--no-pooled-tail" if not flags.gmn_pooled_tail else "readout / path not eligible"})
     res["config"]["ms_per_step_plain_path"] = other_ms       # both restructurings off (FLAGS.gmn_shared_prefix / gmn_pooled_tail)
+    # host cost of ONE fresh batch (merge + CSR + segments + distinct-molecule row map, device work included, synchronised) and
+    # the step time with a fresh batch built for every step under the previous one
+    res["config"]["batch_build_ms"] = build_ms
+    res["config"]["ms_per_step_incl_batch_build"] = incl_ms
+    res["value_incl_batch_build"] = (pairs_per_step / (incl_ms * 1e-3)) if incl_ms else None
     if want_roofline and rank == 0:
         ms, work, names = timer.result()
         mult, peak = MFMA_OF[transform]
@@ -981,6 +1058,10 @@ def main():
                           "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"]},
                "config": dict(res["config"], baseline_config_index=args.config),
                "roofline": res.get("roofline")}
+        if res.get("interaction_gather"):
+            out["interaction_gather"] = res["interaction_gather"]
+        if res.get("value_incl_batch_build") is not None:
+            out["value_incl_batch_build"] = res["value_incl_batch_build"]
         if not args.no_extra and D.world == 1:
             extra = {}
             if args.config != 1:
@@ -988,6 +1069,12 @@ def main():
                 r1 = run_bilevel(1, args, D, transform, 50, 10, 0.3, want_roofline=True)
                 extra["configs_1"] = {"value": r1["value"], "unit": "pairs/s", "ms_per_step": r1["ms_per_step"],
                                       "workload": r1["config"]["workload"], "roofline": r1.get("roofline")}
+            if args.config != 3:
+                # the bi-level path at scale on one GPU (BASELINE configs[3] at N = 1: 100 k drugs, 4 M atoms, d = 256)
+                r3 = run_bilevel(3, args, D, transform, 10, 3, 0.2, want_roofline=True)
+                extra["configs_3_n1"] = {"value": r3["value"], "unit": "pairs/s", "ms_per_step": r3["ms_per_step"],
+                                         "workload": r3["config"]["workload"], "roofline": r3.get("roofline"),
+                                         "interaction_gather": r3.get("interaction_gather")}
             extra.update(micro_roofline(D.device))
             out["extra"] = extra
         if not args.no_cpu_baseline:

@@ -16,7 +16,7 @@ from .config import FLAGS
 __all__ = [
     "CSR", "csr_from_edge_index", "segments_from_batch", "spmm_sum", "linear",
     "gat_conv", "gat_transform", "gat_from_transform", "gcn_conv", "segment_reduce", "segment_reduce_multi", "gmn_match", "edge_relu_sum", "row_absmax", "linear_writes_amax", "linear_h3_preferred",
-    "row_degree", "link_pred_head", "pack_weight_x6", "pack_weight_h3", "pack_weight_h3g", "gin_layer_h3", "gin_layer_h3_supported", "gin_layer_h3_codes", "gin_layer_h3_codes_supported", "linear_x6_supported", "gin_layer_x6", "gin_layer_x6_supported", "gin_stack", "molecule_tiles", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
+    "row_degree", "link_pred_head", "gat_aggregate", "pack_weight_x6", "pack_weight_h3", "pack_weight_h3g", "gin_layer_h3", "gin_layer_h3_supported", "gin_layer_h3_codes", "gin_layer_h3_codes_supported", "linear_x6_supported", "gin_layer_x6", "gin_layer_x6_supported", "gin_stack", "molecule_tiles", "gin_layer", "gin_layer_supported", "pair_gather_normalize", "l2_normalize_rows", "scatter_rows",
     "require_device",
 ]
 
@@ -608,16 +608,24 @@ def gat_from_transform(csr, h, sc, bias, group="src", slope=0.2, act="identity",
         raise ValueError("blgnn: scores must be a contiguous [2, n] tensor")
     stats = torch.empty((2, n), dtype=torch.float32, device=h.device)
     s_dst, s_src, mx, den = sc[0].data_ptr(), sc[1].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr()
-    s = _stream()
-    hp, ldh = _mat(h, "h")
     call("blgnn_gat_softmax_stats", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, s_dst, s_src, n,
-         GAT_GROUP[group], float(slope), mx, den, s)
+         GAT_GROUP[group], float(slope), mx, den, _stream())
+    return gat_aggregate(csr, h, sc, stats, bias, group, slope, act, act_param, bn_scale, bn_shift, out, accumulate, rows)
+
+
+def gat_aggregate(csr, h, sc, stats, bias, group="src", slope=0.2, act="identity", act_param=None,
+                  bn_scale=None, bn_shift=None, out=None, accumulate=False, rows=None):
+    """The weighted neighbour sum of GATConv (blgnn_gat_aggregate: the interaction-level gather) on a transformed table
+    with its scores ``sc`` [2, n] and softmax statistics ``stats`` [2, n] (max, denominator per group)."""
+    n, d = h.shape
+    hp, ldh = _mat(h, "h")
     y = _out(out, n, d, h)
     yp, ldy = _mat(y, "out")
-    call("blgnn_gat_aggregate", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, hp, ldh, s_dst, s_src,
-         mx, den, GAT_GROUP[group], float(slope), yp, ldy, n, d, _vec(bias, "bias"), _act(act),
-         _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"), _vec(bn_shift, "bn_shift"),
-         int(bool(accumulate)), _vec(rows, "rows", torch.int64), 0 if rows is None else rows.numel(), s)
+    call("blgnn_gat_aggregate", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, hp, ldh, sc[0].data_ptr(),
+         sc[1].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), GAT_GROUP[group], float(slope), yp, ldy, n, d,
+         _vec(bias, "bias"), _act(act), _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"),
+         _vec(bn_shift, "bn_shift"), int(bool(accumulate)), _vec(rows, "rows", torch.int64),
+         0 if rows is None else rows.numel(), _stream())
     return y
 
 
