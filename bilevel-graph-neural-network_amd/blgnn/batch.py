@@ -201,9 +201,13 @@ class BatchData(object):
                 inst_off = np.concatenate([[0], np.cumsum(inst_sizes)])
                 n = int(inst_off[-1])
                 assert n == self.merge_data['merge'].x.shape[0]
-                row_map = np.repeat(u_off[inst_u] - inst_off[:-1], inst_sizes) + np.arange(n, dtype=np.int64)
+                # row of merged atom r (instance i) in the distinct graph = u_off[inst_u[i]] + (r - inst_off[i]): expanded
+                # on the device from two [G] arrays
                 dev = self.merge_data['merge'].x.device
-                sm = SharedMolecules(um["merge"], torch.as_tensor(row_map.astype(np.int32)).to(dev))
+                host = torch.as_tensor(np.stack([u_off[inst_u] - inst_off[:-1], inst_sizes]))
+                delta_t, isz_t = host.to(dev, non_blocking=True).unbind(0)
+                row_map = torch.repeat_interleave(delta_t, isz_t, output_size=n) + torch.arange(n, dtype=torch.int64, device=dev)
+                sm = SharedMolecules(um["merge"], row_map.to(torch.int32))
             self._shared = sm
         return sm or None
 

@@ -176,7 +176,10 @@ class GMNPropagator(nn.Module):
         mx = getattr(merge, "_max_graph_nodes", None)
         if mx is None:
             ind = batch_data.merge_data.get('ind_list') if hasattr(batch_data.merge_data, "get") else None
-            mx = max((int(e) - int(s) for s, e in ind), default=0) if ind else 0
+            if ind is not None and hasattr(ind, "sizes"):
+                mx = int(ind.sizes().max()) if len(ind) else 0
+            else:
+                mx = max((int(e) - int(s) for s, e in ind), default=0) if ind else 0
             merge._max_graph_nodes = mx
         return mx
 
@@ -187,7 +190,7 @@ class GMNPropagator(nn.Module):
         po = getattr(merge, "_match_pair_order", None)
         if po is None and hasattr(ops, "match_pair_order"):
             ind = batch_data.merge_data.get('ind_list') if hasattr(batch_data.merge_data, "get") else None
-            po = ops.match_pair_order(ind, device) if ind else None
+            po = ops.match_pair_order(ind, device) if ind is not None and len(ind) else None
             merge._match_pair_order = po
         return po
 

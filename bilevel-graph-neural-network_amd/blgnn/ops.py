@@ -712,7 +712,8 @@ def match_pair_order(ind_list, device):
     """-> (order int32 device tensor, counts int32[4] numpy): the pair indices of a batch grouped by the size of their
     larger graph (<= 32, <= 64, <= 128, larger), from the host-side list of node ranges (src/merged_graph.py:56-57)."""
     import numpy as np
-    sizes = np.asarray([int(e) - int(s) for s, e in ind_list], dtype=np.int64)
+    sizes = ind_list.sizes() if hasattr(ind_list, "sizes") else \
+        np.asarray([int(e) - int(s) for s, e in ind_list], dtype=np.int64)
     big = np.maximum(sizes[0::2], sizes[1::2][:len(sizes[0::2])]) if len(sizes) else sizes
     cls = np.where(big <= 0, 4, np.where(big <= 32, 0, np.where(big <= 64, 1, np.where(big <= 128, 2, 3))))
     order = np.argsort(cls, kind="stable")
