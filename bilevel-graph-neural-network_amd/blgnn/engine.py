@@ -134,7 +134,7 @@ class BiLevelEngine(object):
 
     def __init__(self, model, lower_batch, upper_batches, graph, sharded=None, world_size=1,
                  use_graph=True, overlap=True, fuse_lower=None, readout_with_upper=None, lower_cus_per_xcd=None,
-                 exchange_transformed=None, prune_last=None):
+                 exchange_transformed=None, prune_last=None, parity_streams=False):
         from .config import FLAGS
         k = FLAGS.last_lower_lyr_num
         self.model = model
@@ -245,6 +245,13 @@ class BiLevelEngine(object):
         # never sit on a stream this engine destroys (close()), so the id copies run on an ordinary side
         # stream and the interaction-level stream waits for an event.
         self.stream_c = torch.cuda.Stream(device=dev) if self.overlap else None
+        # ``parity_streams``: the two pipeline parities on UNRELATED stream pairs, ordered by nothing but the events of
+        # ``step()`` (diagnostic: tests/test_gpu_model.py checks that the parities' graphs touch no common buffer that
+        # either writes -- by default both parities' sweeps share stream L and both interaction passes stream U, which
+        # would hide such a buffer).  Not a speed-up: measured 0.34 vs 0.20 ms per step at configs[1] in round 3.
+        self.parity_streams = bool(parity_streams and self.overlap)
+        self._sl = [self.stream_l, torch.cuda.Stream(device=dev) if self.parity_streams else self.stream_l]
+        self._su = [self.stream_u, torch.cuda.Stream(device=dev) if self.parity_streams else self.stream_u]
         self.ev_lower = [None] * self.parities
         self.ev_upper = [None] * self.parities
         self.ev_ids = [None] * self.parities
@@ -446,35 +453,35 @@ class BiLevelEngine(object):
         p = self.step_no & 1
         self.step_no += 1
         cur = torch.cuda.current_stream()
-        with torch.cuda.stream(self.stream_l):
+        sl, su = self._sl[p], self._su[p]
+        with torch.cuda.stream(sl):
             if self.ev_upper[p] is not None:                   # init_x[p] is free once step k-2 scored
-                self.stream_l.wait_event(self.ev_upper[p])
+                sl.wait_event(self.ev_upper[p])
             else:
-                self.stream_l.wait_stream(cur)
+                sl.wait_stream(cur)
             self.g_lower[p].replay()
             self.exchange(self.pooled[p], p)
             self.ev_lower[p] = torch.cuda.Event()
-            self.ev_lower[p].record(self.stream_l)
+            self.ev_lower[p].record(sl)
         with torch.cuda.stream(self.stream_c):
             if self.ev_upper[p] is not None:                   # ids_dev[p] is free once step k-2 scored
                 self.stream_c.wait_event(self.ev_upper[p])
             else:
                 self.stream_c.wait_stream(cur)
             self._feed(which, p)
-        with torch.cuda.stream(self.stream_u):
-            self.stream_u.wait_event(self.ev_ids[p])
-            self.stream_u.wait_event(self.ev_lower[p])
+        with torch.cuda.stream(su):
+            su.wait_event(self.ev_ids[p])
+            su.wait_event(self.ev_lower[p])
             self.g_upper[p].replay()
             self.ev_upper[p] = torch.cuda.Event()
-            self.ev_upper[p].record(self.stream_u)
+            self.ev_upper[p].record(su)
         return self.outs[p]
 
     def synchronize(self):
         if self.overlap and self.stream_l is not None:
             cur = torch.cuda.current_stream()
-            cur.wait_stream(self.stream_l)
-            cur.wait_stream(self.stream_u)
-            cur.wait_stream(self.stream_c)
+            for st in set(self._sl + self._su + [self.stream_c]):
+                cur.wait_stream(st)
         torch.cuda.synchronize()
 
     def close(self):
@@ -490,6 +497,7 @@ class BiLevelEngine(object):
         self.ev_upper = [None] * self.parities
         self.ev_ids = [None] * self.parities
         self.stream_l = self.stream_u = self.stream_c = None
+        self._sl = self._su = [None, None]
         if self._masked is not None:
             self._masked.close()
             self._masked = None

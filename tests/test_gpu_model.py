@@ -302,6 +302,57 @@ def test_engine_graph_replay_and_two_stream_overlap_match_eager(device):
             eng.step(0)
 
 
+def test_engine_parities_on_unrelated_streams_match_eager(device):
+    """The engine's double buffering must not lean on stream order: by default both parities' sweeps share one stream
+    and both interaction passes another, which would serialise -- and hide -- any buffer the two parities' graphs both
+    touch.  Here each parity replays its graphs on its OWN stream pair (``parity_streams``), ordered by nothing but the
+    events of ``step()``; a long blocker holds back one parity at a time so that the other parity's sweep AND
+    interaction pass run to completion beside it, and every step's scores must be the eager forward's, bit for bit.
+    (Round 3's twin-stream experiment produced wrong scores in a harness that also REWROTE the sweep's input features
+    per step on the sweep's stream: the merged atom features are the one buffer both parities' sweeps read, and nothing
+    but the shared stream ordered that rewrite against the other parity's sweep.  The engine itself never writes them:
+    second half of this test.)"""
+    from blgnn.engine import BiLevelEngine
+    ds = blgnn.make_synthetic(200, 1500, seed=27, device=device)
+    flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin",
+                             higher_level_gnn_type="gat", D_lower=64, D_higher=64, device=device,
+                             fuse_readout=False)   # bitwise comparisons: no float atomics in the readout
+    model, data = build(flags, ds, seed=6)
+    lower = blgnn.BatchData(all_molecule_pairs(ds.molecules.gids), ds, is_train=False, ignore_pairs=True)
+    g = ds.interaction_combo_nxgraph
+    g.init_x = torch.zeros((ds.num_graphs(), 5 * 64), device=device)
+    ds.init = True
+    rng = np.random.default_rng(4)
+    batches = [ds.pair_gids[rng.choice(len(ds.pair_gids), 96, replace=False)] for _ in range(8)]
+    template = blgnn.BatchData(batches[0], ds, is_train=False)
+    plain = BiLevelEngine(model, lower, template, g, use_graph=False)
+    refs = [plain.eager_step(b).clone() for b in batches]
+    blk_a, blk_b = torch.randn(4096, 4096, device=device), torch.randn(4096, 4096, device=device)
+    for fused_readout in (False, True):
+        flags.fuse_readout = fused_readout
+        blgnn.set_flags(flags)
+        with BiLevelEngine(model, lower, template, g, use_graph=True, overlap=True, parity_streams=True) as eng:
+            assert eng.parity_streams and eng._sl[0] is not eng._sl[1] and eng._su[0] is not eng._su[1]
+            eng.capture()
+            got = []
+            for k, b in enumerate(batches):
+                p = k & 1
+                # hold back this parity (its sweep on even rounds, its interaction pass on odd ones): the next step, of the
+                # other parity, overtakes it completely
+                with torch.cuda.stream(eng._sl[p] if (k // 2) % 2 == 0 else eng._su[p]):
+                    for _ in range(6):
+                        torch.mm(blk_a, blk_b)
+                o = eng.step(b)
+                with torch.cuda.stream(eng._su[p]):
+                    got.append(o.clone())                   # the score buffer is reused two steps later
+            eng.synchronize()
+            for k, (o, r) in enumerate(zip(got, refs)):
+                if fused_readout:                           # float atomics in the pooled rows: rounding, not bits
+                    assert max_err(o, r) < 1e-6, k
+                else:
+                    assert torch.equal(o, r), k
+
+
 def test_engine_exchange_after_first_transform_is_bitwise_the_replicated_forward(device):
     """multi-GPU decomposition, run at one rank: the first interaction layer's row-wise half (h = pooled @ W and
     the two attention scores) applied to the rank's own pooled rows, the [N, d + 2] table exchanged instead of
