@@ -645,12 +645,7 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
     batches = []
     for _ in range(nb):
         b = BatchData(ds.pair_gids[rng.choice(len(ds.pair_gids), size=batch, replace=False)], ds,
-                      is_train=False, unique_graphs=False)
-        b.merge_data['merge'].csr()
-        b.merge_data['merge'].segments()
-        sm = b.shared_molecules()                          # distinct molecules + row map: part of the batch, like the CSR
-        if sm is not None:
-            sm.graph.csr()
+                      is_train=False, unique_graphs=False).prepare()   # CSR, segments, distinct molecules + row map, pair order
         batches.append(b)
     Nn = int(np.mean([b.merge_data['merge'].x.shape[0] for b in batches]))
     nnz = int(np.mean([b.merge_data['merge'].edge_index.shape[1] for b in batches]))
@@ -729,12 +724,7 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
             def build():
                 with torch.cuda.stream(side):
                     b = BatchData(ds.pair_gids[rng.choice(len(ds.pair_gids), size=batch, replace=False)], ds,
-                                  is_train=False, unique_graphs=False)
-                    b.merge_data['merge'].csr()
-                    b.merge_data['merge'].segments()
-                    sm = b.shared_molecules()
-                    if sm is not None:
-                        sm.graph.csr()
+                                  is_train=False, unique_graphs=False).prepare()
                 return b
 
             def forward_on(b):

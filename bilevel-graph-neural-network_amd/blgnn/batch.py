@@ -211,6 +211,26 @@ class BatchData(object):
             self._shared = sm
         return sm or None
 
+    def prepare(self):
+        """Build every device-side layout a forward derives from the host-side batch -- CSR, segment offsets, the int32
+        batch vector, the distinct-molecule graph + row map and (pair batches) the cross-graph attention's size-class pair
+        order -- NOW, on the current stream.  Each is otherwise built on first use inside the forward, where its
+        host-to-device copy makes the host wait for the kernels already enqueued: a loop that builds batch k + 1 on a side
+        stream while batch k runs calls this at build time.  -> self"""
+        m = self.merge_data['merge']
+        m.csr()
+        m.segments()
+        m.row_graph()
+        sm = self.shared_molecules()
+        if sm is not None:
+            sm.graph.csr()
+            sm.graph.segments()
+        if not self.unique_graphs and len(self.merge_data['ind_list']) % 2 == 0:
+            from .layers_gmn import GMNPropagator
+            GMNPropagator._max_nodes(self)
+            GMNPropagator._pair_order(self, m.x.device)
+        return self
+
     def interaction_rows_of_batch_graphs(self):
         """gs_map[gid] for every graph of the merged batch, int32 on the device."""
         rows = getattr(self, "_graph_rows", None)
