@@ -67,9 +67,17 @@ class LinkPred(nn.Module):
         ops.require_device(ins, "ins")
         ids = getattr(batch_data, "_pair_row_ids", None)
         if ids is None:
-            host = self.pair_row_ids(batch_data)
-            ids = (torch.as_tensor(np.ascontiguousarray(host[:, 0])).to(ins.device),
-                   torch.as_tensor(np.ascontiguousarray(host[:, 1])).to(ins.device))
+            if not self.batch_unique_graphs:
+                # pair mode (layers_link_pred.py:53-54: ids = arange over the batch's graphs, pair i = graphs 2 i, 2 i + 1):
+                # built on the device -- a host-to-device copy HERE, at the end of the forward, makes the host wait for
+                # every kernel the forward has enqueued (16 ms per fresh batch at configs[2], measured)
+                n2 = 2 * int(len(batch_data.batch_gids))
+                ids = (torch.arange(0, n2, 2, dtype=torch.int64, device=ins.device),
+                       torch.arange(1, n2, 2, dtype=torch.int64, device=ins.device))
+            else:
+                host = self.pair_row_ids(batch_data)
+                ids = (torch.as_tensor(np.ascontiguousarray(host[:, 0])).to(ins.device),
+                       torch.as_tensor(np.ascontiguousarray(host[:, 1])).to(ins.device))
             batch_data._pair_row_ids = ids
         ids1, ids2 = ids
         mlp = getattr(self, "mlp_concat", None)
