@@ -65,6 +65,13 @@ CONFIGS = {
             dataset="drugbank", edge_types=1,
             name="synthetic 1M interaction edges, lower GIN + GMN x3, d=512, 8192 edge pairs per step over all "
                  "GPUs, pair mode (BASELINE configs[4])"),
+    # not a BASELINE config: the DrugCombo interaction level (MetaLayerWrapper + NodeModelAggrByEdge('gat'), one
+    # GATConv per edge type summed) at the real data's size -- 3 376 molecules, 50 263 labelled pairs over two edge types --
+    # so that every hot-path row has a number (``extra.drugcombo_interaction_level``)
+    5: dict(kind="bilevel", shape="drugcombo", drugs=3376, pairs=50263, d=128, batch=4096, scaling="weak",
+            dataset="drugcombo", edge_types=2,
+            name="DrugCombo-shape bi-level: lower GIN x5 + MetaLayer (GAT per edge type, summed) x3 + multi-label head, "
+                 "d=128, batch=4096 edge pairs (interaction level of SURVEY 8a10; not a BASELINE config)"),
 }
 
 
@@ -381,15 +388,17 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
     n_pairs = cfg["pairs"] * (eff_world if weak else 1)
     batch = cfg["batch"] if weak else cfg["batch"] // eff_world
     seed = SEED + cfg_id + 1
-    ds = blgnn.make_synthetic(n_drugs, n_pairs, shape=cfg["shape"], seed=seed, device=device)
-    flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin",
+    edge_types = cfg.get("edge_types", 1)
+    ds = blgnn.make_synthetic(n_drugs, n_pairs, shape=cfg["shape"], seed=seed, device=device, num_edge_types=edge_types)
+    flags = blgnn.make_flags("lower_level_gnn_higher_level", dataset=cfg.get("dataset", "drugbank"),
+                             lower_level_gnn_type="gin",
                              higher_level_gnn_type="gat", D_lower=d, D_higher=d, device=device,
                              batch_size=batch, feature_transform=transform,
                              fuse_readout=not args.no_fuse_readout)
     flags.gin_sp = not getattr(args, "no_gin_sp", False)
     blgnn.set_flags(flags)
     torch.manual_seed(seed)
-    data = blgnn.TrainData(ds, device=device)
+    data = blgnn.TrainData(ds, device=device, num_hyper_edge_feat=3 if edge_types > 1 else 0)
     ds.init_interaction_graph_feats(flags.init_embds, device, flags.d_init)
     model = blgnn.Model(data)
     perturb_bn(model, seed + 1)
@@ -475,7 +484,20 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
         counter[0] = warmup
         elapsed, blocks = timed_blocks(run_block, min_seconds)
         preds = last[0]
-        assert preds.shape == (batch, 1) and bool(torch.isfinite(preds).all())
+        assert preds.shape[0] == batch and bool(torch.isfinite(preds).all())
+        # the interaction level + pair scorer alone: the captured upper graph replayed back to back (GPU time per pass)
+        upper_ms = None
+        if engine.use_graph and engine.g_upper[0] is not None:
+            engine.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(3):
+                engine.g_upper[0].replay()
+            e0.record()
+            for _ in range(20):
+                engine.g_upper[0].replay()
+            e1.record()
+            torch.cuda.synchronize()
+            upper_ms = e0.elapsed_time(e1) / 20
 
         # HIP events cannot sit inside a replayed graph: the dominant kernel is timed over K steps launched
         # eagerly right after the timed region (same inputs, same stream).  A long matmul is queued ahead of
@@ -509,6 +531,7 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
                       "lower_cus_per_xcd": engine.lower_cus_per_xcd, "fused_lower_stack": engine.fused is not None,
                       "exchange": ("first interaction layer's transform of the pooled rows [N_r, d+2]"
                                    if engine.exchange_transformed else "pooled rows [N_r, D_pool]"),
+                      "interaction_level_ms": upper_ms,
                       "parallelism": "molecule shards x%d + all-gather(pooled) + pair shards" % world}}
     if want_roofline and rank == 0:
         ms, work, names = timer.result()
@@ -1076,6 +1099,14 @@ def main():
                 extra["configs_3_n1"] = {"value": r3["value"], "unit": "pairs/s", "ms_per_step": r3["ms_per_step"],
                                          "workload": r3["config"]["workload"], "roofline": r3.get("roofline"),
                                          "interaction_gather": r3.get("interaction_gather")}
+            fresh_pools()
+            r5 = run_bilevel(5, args, D, transform, 50, 10, 0.3, want_roofline=False)
+            extra["drugcombo_interaction_level"] = {
+                "workload": r5["config"]["workload"], "ms_per_step": r5["ms_per_step"], "value": r5["value"], "unit": "pairs/s",
+                "interaction_level_ms": r5["config"]["interaction_level_ms"],
+                "what": "interaction_level_ms = LoadInteraction + 3 x MetaLayerWrapper(NodeModelAggrByEdge('gat'): one GATConv "
+                        "per edge type, summed in the aggregation epilogue) + multi-label pair scorer on %d interaction nodes, "
+                        "captured graph replayed back to back" % r5["config"]["drugs"]}
             fresh_pools()
             extra.update(micro_roofline(D.device))
             out["extra"] = extra

@@ -49,9 +49,13 @@ struct GatherArgs {
     // epilogue
     Epilogue epi;
     int32_t accumulate;
-    // optional row subset (k_gather_wide only): compute rows row_list[0 .. n_list) instead of 0 .. n
+    // optional row subset (k_gather_wide / k_gather_wave only): compute rows row_list[0 .. n_list) instead of 0 .. n
     const int64_t *row_list;
     int32_t n_list;
+    // degree window (k_gather_wave / k_gather_wide as a pair: every row is computed by exactly one of them): rows with fewer
+    // than deg_min or more than deg_max edges are left alone
+    int32_t deg_min = 0, deg_max = 0x7fffffff;
+    int32_t hub_blocks = 0;            // k_gather_wave: the first hub_blocks workgroups compute the rows above deg_max
 };
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : slope * v; }
@@ -493,12 +497,12 @@ static void launch_spmm_tile(const GatherArgs &A, hipStream_t s) {
 // ~20 us for the upper GAT of the DrugBank-shape graph.
 constexpr int WIDE_EDGES = 256;
 
+// one output row by the whole 256-thread workgroup (the body of k_gather_wide; also the hub rows of k_gather_wave)
 template <int MODE, int LG, int CH>
-__global__ void __launch_bounds__(256) k_gather_wide(const GatherArgs A) {
+__device__ __forceinline__ void wide_row(const GatherArgs &A, int row, float4 *part4) {
     constexpr int S = WAVE / LG;                 // edge slots per wave
     constexpr int NSLOT = 4 * S;
     constexpr int U = CH <= 1 ? 8 : (CH <= 2 ? 4 : 2);   // neighbour rows in flight per slot
-    extern __shared__ float4 part4[];            // [4][d4] float4, then the parked edges
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
     const int sub = lane / LG, l = lane % LG;
     const int slot = wid * S + sub;
@@ -507,85 +511,253 @@ __global__ void __launch_bounds__(256) k_gather_wide(const GatherArgs A) {
     float *ws = reinterpret_cast<float *>(js + WIDE_EDGES);
     const float4 *__restrict__ X = reinterpret_cast<const float4 *>(A.x);
     const int64_t ldx4 = A.ldx >> 2, ldy4 = A.ldy >> 2, ldp4 = A.ldp >> 2;
-
-    const int nrows = A.row_list ? A.n_list : A.n;
-    for (int it = blockIdx.x; it < nrows; it += gridDim.x) {
-        const int row = A.row_list ? (int)A.row_list[it] : it;         // (a row listed twice is computed twice: same values)
-        EdgeCtx<MODE> ctx;
-        ctx.init(A, row);
-        float4 acc[CH], prow[CH];
-        bool ok[CH];
+    EdgeCtx<MODE> ctx;
+    ctx.init(A, row);
+    float4 acc[CH], prow[CH];
+    bool ok[CH];
 #pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            ok[k] = (l + k * LG) < d4;
-            acc[k] = f4_zero();
-            prow[k] = f4_zero();
+    for (int k = 0; k < CH; ++k) {
+        ok[k] = (l + k * LG) < d4;
+        acc[k] = f4_zero();
+        prow[k] = f4_zero();
+    }
+    if (MODE == MODE_RELU) {
+        const float4 *P = reinterpret_cast<const float4 *>(A.p) + (int64_t)row * ldp4;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) if (ok[k]) prow[k] = P[l + k * LG];
+    } else if (slot == 0) {
+        const float sw = ctx.self_w(A, row);
+        if (sw != 0.f) {
+            const float4 *Sx = X + (int64_t)row * ldx4;
+#pragma unroll
+            for (int k = 0; k < CH; ++k) if (ok[k]) { float4 v = Sx[l + k * LG]; f4_fma(acc[k], sw, v); }
         }
-        if (MODE == MODE_RELU) {
-            const float4 *P = reinterpret_cast<const float4 *>(A.p) + (int64_t)row * ldp4;
-#pragma unroll
-            for (int k = 0; k < CH; ++k) if (ok[k]) prow[k] = P[l + k * LG];
-        } else if (slot == 0) {
-            const float sw = ctx.self_w(A, row);
-            if (sw != 0.f) {
-                const float4 *Sx = X + (int64_t)row * ldx4;
-#pragma unroll
-                for (int k = 0; k < CH; ++k) if (ok[k]) { float4 v = Sx[l + k * LG]; f4_fma(acc[k], sw, v); }
-            }
+    }
+    const int e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
+    for (int base = e0; base < e1; base += WIDE_EDGES) {
+        {   // (a) one edge per thread
+            const int ee = base + threadIdx.x;
+            int j = row;
+            float w = 0.f;
+            if (ee < e1) { j = A.col[ee]; w = ctx.edge_w(A, row, j, ee); }
+            js[threadIdx.x] = j;
+            ws[threadIdx.x] = w;
         }
-        const int e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
-        for (int base = e0; base < e1; base += WIDE_EDGES) {
-            {   // (a) one edge per thread
-                const int ee = base + threadIdx.x;
-                int j = row;
-                float w = 0.f;
-                if (ee < e1) { j = A.col[ee]; w = ctx.edge_w(A, row, j, ee); }
-                js[threadIdx.x] = j;
-                ws[threadIdx.x] = w;
+        __syncthreads();
+        const int cnt = (e1 - base) < WIDE_EDGES ? (e1 - base) : WIDE_EDGES;
+        for (int t = slot; t < cnt; t += U * NSLOT) {
+            int j[U];
+            float w[U];
+            float4 v[U][CH];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int tt = t + u * NSLOT;
+                j[u] = tt < cnt ? js[tt] : row;
+                w[u] = tt < cnt ? ws[tt] : 0.f;
             }
-            __syncthreads();
-            const int cnt = (e1 - base) < WIDE_EDGES ? (e1 - base) : WIDE_EDGES;
-            for (int t = slot; t < cnt; t += U * NSLOT) {
-                int j[U];
-                float w[U];
-                float4 v[U][CH];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int tt = t + u * NSLOT;
-                    j[u] = tt < cnt ? js[tt] : row;
-                    w[u] = tt < cnt ? ws[tt] : 0.f;
+            for (int u = 0; u < U; ++u) {
+                if (w[u] != 0.f) {
+                    const float4 *R = X + (int64_t)j[u] * ldx4;
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) if (ok[k]) v[u][k] = R[l + k * LG];
                 }
+            }
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (w[u] != 0.f) {
-                        const float4 *R = X + (int64_t)j[u] * ldx4;
+            for (int u = 0; u < U; ++u) {
+                if (w[u] != 0.f) {
 #pragma unroll
-                        for (int k = 0; k < CH; ++k) if (ok[k]) v[u][k] = R[l + k * LG];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (w[u] != 0.f) {
-#pragma unroll
-                        for (int k = 0; k < CH; ++k) {
-                            if (!ok[k]) continue;
-                            if (MODE == MODE_RELU) {
-                                acc[k].x += fmaxf(prow[k].x + v[u][k].x, 0.f);
-                                acc[k].y += fmaxf(prow[k].y + v[u][k].y, 0.f);
-                                acc[k].z += fmaxf(prow[k].z + v[u][k].z, 0.f);
-                                acc[k].w += fmaxf(prow[k].w + v[u][k].w, 0.f);
-                            } else if (MODE == MODE_SUM && !A.w) {
-                                f4_add(acc[k], v[u][k]);
-                            } else {
-                                f4_fma(acc[k], w[u], v[u][k]);
-                            }
+                    for (int k = 0; k < CH; ++k) {
+                        if (!ok[k]) continue;
+                        if (MODE == MODE_RELU) {
+                            acc[k].x += fmaxf(prow[k].x + v[u][k].x, 0.f);
+                            acc[k].y += fmaxf(prow[k].y + v[u][k].y, 0.f);
+                            acc[k].z += fmaxf(prow[k].z + v[u][k].z, 0.f);
+                            acc[k].w += fmaxf(prow[k].w + v[u][k].w, 0.f);
+                        } else if (MODE == MODE_SUM && !A.w) {
+                            f4_add(acc[k], v[u][k]);
+                        } else {
+                            f4_fma(acc[k], w[u], v[u][k]);
                         }
                     }
                 }
             }
-            __syncthreads();                     // parked edges consumed before the next pass
         }
-        // slots of one wave -> lane group 0
+        __syncthreads();                     // parked edges consumed before the next pass
+    }
+    // slots of one wave -> lane group 0
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+#pragma unroll
+        for (int off = LG; off < WAVE; off <<= 1) {
+            acc[k].x += __shfl_xor(acc[k].x, off, WAVE);
+            acc[k].y += __shfl_xor(acc[k].y, off, WAVE);
+            acc[k].z += __shfl_xor(acc[k].z, off, WAVE);
+            acc[k].w += __shfl_xor(acc[k].w, off, WAVE);
+        }
+    }
+    if (sub == 0) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k) if (ok[k]) part4[wid * d4 + l + k * LG] = acc[k];
+    }
+    __syncthreads();
+    float4 *Y = reinterpret_cast<float4 *>(A.y) + (int64_t)row * ldy4;
+    for (int c4 = threadIdx.x; c4 < d4; c4 += blockDim.x) {
+        float4 a = part4[c4], b = part4[d4 + c4], c = part4[2 * d4 + c4], dd = part4[3 * d4 + c4];
+        float t[4] = {(a.x + b.x) + (c.x + dd.x), (a.y + b.y) + (c.y + dd.y),
+                      (a.z + b.z) + (c.z + dd.z), (a.w + b.w) + (c.w + dd.w)};
+        if (MODE == MODE_GCN || MODE == MODE_GAT) {
+            const float4 o = A.accumulate ? Y[c4] : f4_zero();
+            const float oo[4] = {o.x, o.y, o.z, o.w};
+            const Epilogue &E = A.epi;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = 4 * c4 + q;
+                float val = t[q] + (E.bias ? E.bias[c] : 0.f) + oo[q];
+                float sl = (E.act == BLGNN_ACT_PRELU && E.act_param) ? E.act_param[c] : 0.f;
+                val = apply_act(val, E.act, sl);
+                if (E.bn_scale) val = fmaf(val, E.bn_scale[c], E.bn_shift ? E.bn_shift[c] : 0.f);
+                t[q] = val;
+            }
+        }
+        Y[c4] = make_float4(t[0], t[1], t[2], t[3]);
+    }
+    __syncthreads();
+}
+
+template <int MODE, int LG, int CH>
+__global__ void __launch_bounds__(256) k_gather_wide(const GatherArgs A) {
+    extern __shared__ float4 part4[];            // [4][d4] float4, then the parked edges
+    const int nrows = A.row_list ? A.n_list : A.n;
+    for (int it = blockIdx.x; it < nrows; it += gridDim.x) {
+        const int row = A.row_list ? (int)A.row_list[it] : it;         // (a row listed twice is computed twice: same values)
+        const int deg = A.rowptr[row + 1] - A.rowptr[row];            // (uniform: scalar loads)
+        if (deg < A.deg_min || deg > A.deg_max) continue;
+        wide_row<MODE, LG, CH>(A, row, part4);
+    }
+}
+
+// "One wavefront per row" variant for LARGE high-degree graphs (configs[3]: 100 k interaction nodes, mean degree 21).  The
+// workgroup-per-row kernel above spends a row's time in five dependent round trips (rowptr -> col -> scores -> rows ->
+// LDS combine) and three barriers with 256 threads for ~21 edges: 500 us for 2.25 GB gathered out of a 102 MB
+// Infinity-Cache-resident table = 4.3 TB/s, against 7.4-8.6 TB/s for such gathers (MI355X_MICROARCH.md, "Indexed rows").
+// Here a row belongs to ONE wavefront -- no LDS, no barrier, 32 rows of the graph in flight per CU: its lanes compute the
+// (source, weight) of up to 64 edges at once, then the S = 64 / LG lane groups walk those edges, U neighbour rows in
+// flight per group (row-contiguous 16 B-per-lane loads; with LG = 64 the source index is a scalar and so is the row's
+// base address).  Rows above ``deg_max`` edges (hubs: hundreds of sequential round trips for one wavefront; configs[3] has
+// 107 of them, up to 4 611 edges) are computed by the first ``hub_blocks`` workgroups of the SAME launch with all 256
+// threads per row (as their own launch behind this one they took 180 us after its 358).  The sum of a row is formed in a
+// fixed order (edge order within a lane group, groups combined as a xor butterfly): deterministic.
+constexpr int WAVE_ROW_HUB_DEGREE = 384;
+constexpr int HUB_QUEUE = 1024;                  // rows a hub workgroup scans per round (its LDS queue holds them all)
+constexpr int HUB_BLOCKS = 128;
+
+template <int MODE, int LG, int CH>
+__global__ void __launch_bounds__(256) k_gather_wave(const GatherArgs A) {
+    constexpr int S = WAVE / LG;                 // lane groups = edge slots of the wavefront
+    constexpr int U = CH <= 1 ? 8 : (CH <= 2 ? 4 : 2);   // neighbour rows in flight per slot
+    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+    const int sub = lane / LG, l = lane % LG;
+    const int d4 = A.d >> 2;
+    const float4 *__restrict__ X = reinterpret_cast<const float4 *>(A.x);
+    const int64_t ldx4 = A.ldx >> 2, ldy4 = A.ldy >> 2;
+    const int nrows = A.row_list ? A.n_list : A.n;
+    if ((int)blockIdx.x < A.hub_blocks) {
+        // ---- hub role: the first hub_blocks workgroups (dispatched first, so the longest rows start first) each scan a
+        // slice of the rows for those above deg_max edges and compute them with all 256 threads (wide_row), beside the
+        // other workgroups' one-wavefront rows instead of in a launch behind them
+        extern __shared__ float4 part4[];                        // wide_row's [4][d4] + parked edges, then the hub queue
+        int *queue = reinterpret_cast<int *>(part4 + 4 * d4) + 2 * WIDE_EDGES;      // [0] = count, [1 ..] = rows
+        const int per = (nrows + A.hub_blocks - 1) / A.hub_blocks;
+        const int lo = blockIdx.x * per, hi = lo + per < nrows ? lo + per : nrows;
+        for (int base = lo; base < hi; base += HUB_QUEUE) {
+            if (threadIdx.x == 0) queue[0] = 0;
+            __syncthreads();
+            for (int it = base + threadIdx.x; it < base + HUB_QUEUE && it < hi; it += blockDim.x) {
+                const int r = A.row_list ? (int)A.row_list[it] : it;
+                if (A.rowptr[r + 1] - A.rowptr[r] > A.deg_max) queue[1 + atomicAdd(&queue[0], 1)] = r;
+            }
+            __syncthreads();
+            const int found = queue[0];
+            for (int q = 0; q < found; ++q) wide_row<MODE, LG, CH>(A, queue[1 + q], part4);     // (ends in a barrier)
+            __syncthreads();
+        }
+        return;
+    }
+    const int waves = (gridDim.x - A.hub_blocks) * 4;
+    bool ok[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) ok[k] = (l + k * LG) < d4;
+    for (int it = (blockIdx.x - A.hub_blocks) * 4 + wid; it < nrows; it += waves) {
+        const int row = __builtin_amdgcn_readfirstlane(A.row_list ? (int)A.row_list[it] : it);
+        const int e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
+        if (e1 - e0 > A.deg_max) continue;                      // a hub: the hub role's
+        EdgeCtx<MODE> ctx;
+        ctx.init(A, row);
+        float4 acc[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) acc[k] = f4_zero();
+        if (sub == 0) {
+            const float sw = ctx.self_w(A, row);
+            if (sw != 0.f) {
+                const float4 *Sx = X + (int64_t)row * ldx4;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) if (ok[k]) { const float4 v = Sx[l + k * LG]; f4_fma(acc[k], sw, v); }
+            }
+        }
+        for (int base = e0; base < e1; base += WAVE) {
+            // (a) one edge per lane: source and weight (for GAT the score / max / denominator gathers and the exp)
+            const int ee = base + lane;
+            int j = row;
+            float w = 0.f;
+            if (ee < e1) { j = A.col[ee]; w = ctx.edge_w(A, row, j, ee); }
+            const int cnt = (e1 - base) < WAVE ? (e1 - base) : WAVE;
+            // (b) the lane groups walk the edges, U rows in flight each
+            for (int t0 = 0; t0 < cnt; t0 += U * S) {
+                int jj[U];
+                float ww[U];
+                float4 v[U][CH];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    // past the last edge: the last edge again with weight 0 -- the loads below stay UNCONDITIONAL (a load
+                    // behind a branch makes hipcc wait for every request in flight before the next one: one row in flight
+                    // instead of U), and the repeated row is an L1 hit
+                    if (S == 1) {
+                        const int tt = t0 + u;                                     // uniform: v_readlane, scalar row base
+                        const int tc = tt < cnt ? tt : cnt - 1;
+                        jj[u] = __builtin_amdgcn_readlane(j, tc);
+                        ww[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), tc));
+                        if (tt >= cnt) ww[u] = 0.f;
+                    } else {
+                        const int tt = t0 + u * S + sub;
+                        const int tc = tt < cnt ? tt : cnt - 1;
+                        jj[u] = __shfl(j, tc, WAVE);
+                        ww[u] = __shfl(w, tc, WAVE);
+                        if (tt >= cnt) ww[u] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float4 *R = X + (int64_t)jj[u] * ldx4;
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) v[u][k] = R[ok[k] ? l + k * LG : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        // (a weight of exactly 0 -- a dropped self loop, a slot past the end -- adds nothing, whatever the row holds)
+                        float4 t = acc[k];
+                        if (MODE == MODE_SUM && !A.w) f4_add(t, v[u][k]);
+                        else f4_fma(t, ww[u], v[u][k]);
+                        const bool use = ww[u] != 0.f;
+                        acc[k].x = use ? t.x : acc[k].x; acc[k].y = use ? t.y : acc[k].y;
+                        acc[k].z = use ? t.z : acc[k].z; acc[k].w = use ? t.w : acc[k].w;
+                    }
+                }
+            }
+        }
+        // lane groups -> every lane (xor butterfly: fixed order)
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
 #pragma unroll
@@ -597,32 +769,29 @@ __global__ void __launch_bounds__(256) k_gather_wide(const GatherArgs A) {
             }
         }
         if (sub == 0) {
+            float4 *Y = reinterpret_cast<float4 *>(A.y) + (int64_t)row * ldy4;
 #pragma unroll
-            for (int k = 0; k < CH; ++k) if (ok[k]) part4[wid * d4 + l + k * LG] = acc[k];
-        }
-        __syncthreads();
-        float4 *Y = reinterpret_cast<float4 *>(A.y) + (int64_t)row * ldy4;
-        for (int c4 = threadIdx.x; c4 < d4; c4 += blockDim.x) {
-            float4 a = part4[c4], b = part4[d4 + c4], c = part4[2 * d4 + c4], dd = part4[3 * d4 + c4];
-            float t[4] = {(a.x + b.x) + (c.x + dd.x), (a.y + b.y) + (c.y + dd.y),
-                          (a.z + b.z) + (c.z + dd.z), (a.w + b.w) + (c.w + dd.w)};
-            if (MODE == MODE_GCN || MODE == MODE_GAT) {
-                const float4 o = A.accumulate ? Y[c4] : f4_zero();
-                const float oo[4] = {o.x, o.y, o.z, o.w};
-                const Epilogue &E = A.epi;
+            for (int k = 0; k < CH; ++k) {
+                if (!ok[k]) continue;
+                const int c4 = l + k * LG;
+                float t[4] = {acc[k].x, acc[k].y, acc[k].z, acc[k].w};
+                if (MODE == MODE_GCN || MODE == MODE_GAT) {
+                    const float4 o = A.accumulate ? Y[c4] : f4_zero();
+                    const float oo[4] = {o.x, o.y, o.z, o.w};
+                    const Epilogue &E = A.epi;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = 4 * c4 + q;
-                    float val = t[q] + (E.bias ? E.bias[c] : 0.f) + oo[q];
-                    float sl = (E.act == BLGNN_ACT_PRELU && E.act_param) ? E.act_param[c] : 0.f;
-                    val = apply_act(val, E.act, sl);
-                    if (E.bn_scale) val = fmaf(val, E.bn_scale[c], E.bn_shift ? E.bn_shift[c] : 0.f);
-                    t[q] = val;
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = 4 * c4 + q;
+                        float val = t[q] + (E.bias ? E.bias[c] : 0.f) + oo[q];
+                        const float sl = (E.act == BLGNN_ACT_PRELU && E.act_param) ? E.act_param[c] : 0.f;
+                        val = apply_act(val, E.act, sl);
+                        if (E.bn_scale) val = fmaf(val, E.bn_scale[c], E.bn_shift ? E.bn_shift[c] : 0.f);
+                        t[q] = val;
+                    }
                 }
+                Y[c4] = make_float4(t[0], t[1], t[2], t[3]);
             }
-            Y[c4] = make_float4(t[0], t[1], t[2], t[3]);
         }
-        __syncthreads();
     }
 }
 
@@ -684,8 +853,22 @@ static void launch_wide(const GatherArgs &A, hipStream_t s) {
                        (size_t)A.d * 16 + WIDE_EDGES * 8, s, A);
 }
 
-// rows this heavy on average go one-workgroup-per-row (see k_gather_wide)
+// one launch: one wavefront per row up to WAVE_ROW_HUB_DEGREE edges, the rows above by the hub workgroups
+template <int MODE, int LG, int CH>
+static void launch_wave(GatherArgs A, hipStream_t s) {
+    const int rows = A.row_list ? A.n_list : A.n;
+    A.deg_min = 0; A.deg_max = WAVE_ROW_HUB_DEGREE; A.hub_blocks = HUB_BLOCKS;
+    const int blocks = HUB_BLOCKS + ((rows + 3) / 4 < 256 * 8 ? (rows + 3) / 4 : 256 * 8);
+    hipLaunchKernelGGL((k_gather_wave<MODE, LG, CH>), dim3(blocks), dim3(256),
+                       (size_t)A.d * 16 + WIDE_EDGES * 8 + (HUB_QUEUE + 1) * sizeof(int), s, A);
+}
+
+// rows this heavy on average go one-workgroup-per-row (see k_gather_wide) ...
 constexpr int64_t WIDE_MEAN_DEGREE = 12;
+// ... and, on graphs with at least this many rows to compute, one-wavefront-per-row with the hubs behind it (k_gather_wave);
+// below it a launch has fewer rows than the chip has wavefront slots and the workgroup-per-row kernel's 256 threads per
+// row are the parallelism there is (DrugBank interaction level: 1 326 rows)
+constexpr int WAVE_ROW_MIN_ROWS = 16384;
 
 // row magnitudes of a finished result merged into amax by atomic maximum (fallback of the variants without an amax epilogue)
 __global__ void __launch_bounds__(256) k_row_absmax_merge(const float *__restrict__ y, int64_t ldy, int n, int d,
@@ -707,7 +890,14 @@ static int dispatch(const GatherArgs &A, int64_t nnz, bool extra_aligned, hipStr
     const bool vec = (A.d % 4 == 0) && (A.ldx % 4 == 0) && (A.ldy % 4 == 0) &&
                      aligned16(A.x) && aligned16(A.y) && extra_aligned;
     const int d4 = A.d / 4;
-    if (vec && d4 <= 512 && nnz >= WIDE_MEAN_DEGREE * (int64_t)A.n) {
+    static const bool wave_rows = [] { const char *e = getenv("BLGNN_GATHER_WAVE"); return !(e && e[0] == '0'); }();   // (A/B switch)
+    if (wave_rows && MODE != MODE_RELU && vec && d4 <= 128 && nnz >= WIDE_MEAN_DEGREE * (int64_t)A.n &&
+        (A.row_list ? A.n_list : A.n) >= WAVE_ROW_MIN_ROWS) {
+        if (d4 <= 16) launch_wave<MODE, 16, 1>(A, s);
+        else if (d4 <= 32) launch_wave<MODE, 32, 1>(A, s);
+        else if (d4 <= 64) launch_wave<MODE, 64, 1>(A, s);
+        else launch_wave<MODE, 64, 2>(A, s);
+    } else if (vec && d4 <= 512 && nnz >= WIDE_MEAN_DEGREE * (int64_t)A.n) {
         if (d4 <= 16) launch_wide<MODE, 16, 1>(A, s);
         else if (d4 <= 32) launch_wide<MODE, 32, 1>(A, s);
         else if (d4 <= 64) launch_wide<MODE, 64, 1>(A, s);

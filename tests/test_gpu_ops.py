@@ -523,6 +523,42 @@ def test_convs_on_large_high_degree_graph(device, d):
     assert max_err(ops.spmm_sum(csr, dv(x), 1.0, False), ref) < TOL
 
 
+@pytest.mark.parametrize("d", [64, 128, 256, 320])
+def test_convs_one_wavefront_per_row_with_hub_rows(device, d):
+    """>= 16 384 rows at mean degree 20: blgnn_gat_aggregate / gcn / spmm take the one-wavefront-per-row kernel
+    (k_gather_wave) for rows up to 384 edges and the workgroup-per-row kernel for the hubs behind it; the graph has hub
+    rows of 700 and 1 500 edges, rows of exactly 64 / 65 / 384 / 385 edges (the pass and hand-over boundaries), isolated
+    rows and self loops; a row subset (the pruned last interaction layer) must give the same bits as the full pass"""
+    n = 20000
+    rng = np.random.default_rng(d)
+    e = [rng.integers(0, n - 5, size=(n * 10, 2))]
+    for hub, deg in ((17, 700), (4242, 1500), (100, 64), (101, 65), (102, 384), (103, 385)):
+        nb = rng.choice(n - 5, size=deg, replace=False)
+        e.append(np.stack([np.full(deg, hub), nb], axis=1))
+    ei = torch.as_tensor(blgnn.graph.to_undirected_host(np.concatenate(e), n))
+    x = torch.randn(n, d)
+    W, att, b = torch.randn(d, d) / d ** 0.5, torch.randn(1, 1, 2 * d) / d ** 0.5, torch.randn(d) * 0.1
+    csr = ops.csr_from_edge_index(ei.to(device), n)
+    deg_of = (csr.rowptr[1:] - csr.rowptr[:-1]).cpu()
+    assert int(deg_of.max()) > 1000 and int((deg_of > 384).sum()) >= 3
+    dv = lambda t: t.to(device)
+    for group in ("src", "dst"):
+        ref = oracle.gat_conv(x.double(), ei, W.double(), att.double(), b.double(), group)
+        got = ops.gat_conv(csr, dv(x), dv(W), dv(att), dv(b), group=group)
+        assert max_err(got, ref) < TOL
+        rows = torch.as_tensor(rng.choice(n, size=17000, replace=False), device=device)
+        part = ops.gat_conv(csr, dv(x), dv(W), dv(att), dv(b), group=group, rows=rows,
+                            out=torch.full((n, d), -7.0, device=device))
+        assert torch.equal(part[rows], got[rows])
+        untouched = torch.ones(n, dtype=torch.bool, device=device)
+        untouched[rows] = False
+        assert float((part[untouched] + 7.0).abs().max()) == 0.0
+    ref = oracle.gcn_conv(x.double(), ei, W.double(), b.double())
+    assert max_err(ops.gcn_conv(csr, dv(x), dv(W), dv(b)), ref) < TOL
+    ref = oracle.scatter_add(x[ei[1]].double(), ei[0], n) + x.double()
+    assert max_err(ops.spmm_sum(csr, dv(x), 1.0, False), ref) < TOL
+
+
 def test_gat_conv_molecules_and_accumulate(device):
     ei, _, n = molecule_graph(30, 3)
     d = 64
