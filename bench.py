@@ -960,15 +960,20 @@ def run_train(args, D, transform, steps, warmup):
     import helpers
     from blgnn.batch import BatchData
     from blgnn.forward import all_molecule_pairs, get_initial_embd
-    cfg = CONFIGS[1]
+    # --config 5: the DrugCombo bi-level model (MetaLayer interaction level, multi-label scorer, cross-entropy) under the
+    # same captured iteration; any other --config: the DrugBank BI-GNN (configs[1] shape)
+    combo = args.config == 5
+    cfg = CONFIGS[5 if combo else 1]
     device = D.device
     d, batch = cfg["d"], 2048                                # 2 048 positives + 2 048 sampled negatives = 4 096 scored pairs
-    ds = blgnn.make_synthetic(cfg["drugs"], cfg["pairs"], shape=cfg["shape"], seed=SEED + 7, device=device)
-    flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin", higher_level_gnn_type="gat",
+    ds = blgnn.make_synthetic(cfg["drugs"], cfg["pairs"], shape=cfg["shape"], seed=SEED + 7, device=device,
+                              num_edge_types=cfg.get("edge_types", 1))
+    flags = blgnn.make_flags("lower_level_gnn_higher_level", dataset=cfg.get("dataset", "drugbank"),
+                             lower_level_gnn_type="gin", higher_level_gnn_type="gat",
                              D_lower=d, D_higher=d, device=device, batch_size=batch, feature_transform=transform)
     blgnn.set_flags(flags)
     torch.manual_seed(SEED)
-    data = blgnn.TrainData(ds, device=device)
+    data = blgnn.TrainData(ds, device=device, num_hyper_edge_feat=3 if combo else 0)
     ds.init_interaction_graph_feats(flags.init_embds, device, flags.d_init)
     model = blgnn.Model(data).to(device)
     model.train()
@@ -1008,14 +1013,17 @@ def run_train(args, D, transform, steps, warmup):
            "unit": "pairs/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * el / steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_OF[transform],
            "data": "synthetic",
-           "config": {"workload": "TRAINING, DrugBank-shape DDI, lower GIN x5 + upper GAT x3, d=128: sweep over all %d "
-                                  "drugs with gradients + %d positive and as many sampled negative pairs per step"
+           "config": {"workload": ("TRAINING, DrugCombo-shape bi-level (lower GIN x5 + MetaLayer(GAT per edge type) x3, "
+                                   "multi-label scorer, cross-entropy), d=128: sweep over all %d drugs with gradients + %d "
+                                   "positive and as many sampled negative pairs per step" if combo else
+                                   "TRAINING, DrugBank-shape DDI, lower GIN x5 + upper GAT x3, d=128: sweep over all %d "
+                                   "drugs with gradients + %d positive and as many sampled negative pairs per step")
                                   % (cfg["drugs"], batch),
                       "atoms": int(lower_cache[0].merge_data['merge'].x.shape[0]), "optimizer": "SGD(momentum 0.9)",
                       "iteration": "captured in one HIP graph, replayed per batch (blgnn.TrainStep)" if captured
                                    else "eager (--train-eager)",
                       "loss_first3_mean": first, "loss_last3_mean": last}}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and not combo:
         # the oracle with torch autograd on the host cores: same model, same sizes, bounded number of steps
         cores = usable_cores()
         torch.set_num_threads(cores)

@@ -656,3 +656,50 @@ def test_train_step_replays_invalidate_derived_weight_caches(device):
         assert float((got - want).abs().max()) < 1e-6, rounds
         seen.append(got)
     assert float((seen[0] - seen[1]).abs().max()) > 1e-4         # the second round of replays did change the scores
+
+
+def test_train_step_drugcombo_bilevel_captured_equals_eager(device):
+    """blgnn.TrainStep on the DrugCombo bi-level model (src/config.py:120-123,383-410: MetaLayer interaction level = one
+    GATConv per edge type summed, multi-label scorer, cross-entropy): the captured iteration follows the eager one over
+    four batches (bars: run-to-run variation of the float atomics in the backward kernels, as in the DrugBank test)"""
+    import copy
+    from blgnn.batch import BatchData
+    ds = blgnn.make_synthetic(60, 400, seed=23, device=device, num_edge_types=2, name="drugcombo_syn")
+    flags = blgnn.make_flags("lower_level_gnn_higher_level", dataset="drugcombo", lower_level_gnn_type="gin",
+                             D_lower=64, D_higher=64, device=device, batch_size=32)
+    blgnn.set_flags(flags)
+    torch.manual_seed(3)
+    data = blgnn.TrainData(ds, device=device, num_hyper_edge_feat=3)
+    ds.init_interaction_graph_feats(flags.init_embds, device, flags.d_init)
+    rng = np.random.default_rng(5)
+    batches = []
+    while len(batches) < 5:
+        pos = ds.pair_gids[rng.choice(len(ds.pair_gids), size=32, replace=False)]
+        b = BatchData(pos, ds, sampled_gids=np.unique(pos), is_train=True, rng=rng)
+        if not batches or len(b.batch_gids) == len(batches[0].batch_gids):
+            batches.append(b)
+    results = []
+    for capture in (False, True):
+        torch.manual_seed(3)
+        model = blgnn.Model(data).to(device)
+        model.train()
+        ds.init = False
+        ds.interaction_combo_nxgraph.init_x = None
+        ds.init_interaction_graph_feats(flags.init_embds, device, flags.d_init)
+        opt = torch.optim.SGD([p for k, p in model.named_parameters() if k.startswith("layers.")], lr=0.005, momentum=0.9)
+        ts = blgnn.TrainStep(model, data, opt, copy.copy(batches[0]), capture=capture, warmup=2)
+        assert (ts.graph is not None) == capture
+        if not capture:
+            for _ in range(2):
+                ts.step(batches[0])
+        losses = [float(ts.step(b)) for b in batches[1:]]
+        torch.cuda.synchronize()
+        results.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+    (l0, s0), (l1, s1) = results
+    assert abs(l0[0] - l1[0]) < 2e-6, (l0, l1)
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < 1e-4, (l0, l1)
+    assert l0[-1] != l0[0]
+    for k in s0:
+        if s0[k].is_floating_point():
+            a, b = s0[k].double().cpu(), s1[k].double().cpu()
+            assert float((a - b).abs().max()) / max(1.0, float(a.abs().max())) < 1e-3, k
