@@ -202,8 +202,14 @@ class BiLevelEngine(object):
         self.readout_with_upper = bool(readout_with_upper and self.overlap and world_size == 1
                                        and self.fused is None and len(self.lower_layers) > 1)
         self.lower_acts = [None] * self.parities
+        # The interaction-level pass is short (2.1 ms alone at configs[3]) and the next step's sweep long (20.7 ms); beside
+        # the sweep its kernels wait for workgroup slots the sweep's 62 500 workgroups keep refilling (kernel trace:
+        # k_link_head 0.19 ms alone, 5-9 ms on average beside the sweep).  The short pass runs on a high-priority stream; the
+        # measured effect is small (22.3 vs 22.0 ms/step on a cool device, 31 vs 40 on one that was throttling), it costs nothing.
+        import os
+        prio = -1 if os.environ.get("BLGNN_ENGINE_UPPER_PRIORITY", "1") != "0" else 0
         self.stream_l = torch.cuda.Stream(device=dev) if self.overlap else None
-        self.stream_u = torch.cuda.Stream(device=dev) if self.overlap else None
+        self.stream_u = torch.cuda.Stream(device=dev, priority=prio) if self.overlap else None
         self.lower_cus_per_xcd = None
         self._masked = None
         if self.overlap and lower_cus_per_xcd:

@@ -46,9 +46,10 @@ int main(int argc, char **argv) {
         CK(hipDeviceSynchronize());
         CK(hipMemcpy((variant ? y_old : y_new).data(), y, (size_t)n * N * 4, hipMemcpyDeviceToHost));
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        hipEventRecord(e0); for (int i = 0; i < 20; ++i) run(); hipEventRecord(e1); hipEventSynchronize(e1);
+        const int reps = getenv("GIN_REPS") ? atoi(getenv("GIN_REPS")) : 20;      // (sustained load: GIN_REPS=3000 ~ 2 s)
+        hipEventRecord(e0); for (int i = 0; i < reps; ++i) run(); hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        printf("gin d=%d %d rows (%s): %.1f us per launch\n", N, n, variant ? "one 512-thread workgroup per CU, round 3" : (N == 256 ? "two 256-thread workgroups per CU" : "d = 128 kernel"), ms * 50.0);
+        printf("gin d=%d %d rows (%s): %.1f us per launch over %d launches\n", N, n, variant ? "one 512-thread workgroup per CU, round 3" : (N == 256 ? "two 256-thread workgroups per CU" : "d = 128 kernel"), ms * 1000.0 / reps, reps);
         unsigned long long st[16];
         hipMemcpyFromSymbol(st, HIP_SYMBOL(blgnn::g_gin_stamps), sizeof(st));
         if (variant || N != 256) {
