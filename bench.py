@@ -505,6 +505,9 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
         # execution, not host launch latency.
         roofline = None
         if want_roofline:                       # every rank: eager steps contain the all-gather
+            for i in range(2):                  # untimed: the eager steps' activations come out of the allocator's pools
+                engine.eager_step(fresh[i % pool])  # afterwards (a first eager step pays hipMalloc inside the events)
+            torch.cuda.synchronize()
             timer.enabled = gtimer.enabled = rank == 0
             blk = torch.empty(4096, 8192, device=device)
             blk_w = torch.empty(8192, 8192, device=device)
@@ -762,20 +765,37 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
                 nxt = build()
                 side.synchronize()
             build_ms = 1e3 * (time.perf_counter() - t0) / 3
-            for _ in range(2):                                       # warm the allocator pools of the rotating batches
-                torch.cuda.current_stream().wait_stream(side)
-                forward_on(nxt)
-                nxt = build()
+            # A batch's tensors are allocated on the SIDE stream and read by the forward on the main stream: the caching
+            # allocator would hand their memory to the next side-stream allocation the moment Python drops them, while
+            # the forward that reads them may still be running.  A batch is therefore kept for two more steps, and
+            # dropped only after the side stream has been told to wait for the end of the forward that used it.
+            import collections
+            keep = collections.deque()
+
+            def pipelined_step():
+                nonlocal_nxt = state["nxt"]
+                main = torch.cuda.current_stream()
+                main.wait_stream(side)
+                forward_on(nonlocal_nxt)                             # enqueue the step ...
+                ev = torch.cuda.Event()
+                ev.record(main)
+                keep.append((nonlocal_nxt, ev))
+                if len(keep) > 2:
+                    old, old_ev = keep.popleft()
+                    side.wait_event(old_ev)
+                    del old
+                state["nxt"] = build()                               # ... and build the next batch under it
+            state = {"nxt": nxt}
+            for _ in range(3):                                       # warm the allocator pools of the rotating batches
+                pipelined_step()
             torch.cuda.synchronize()
             D.barrier()
             t0 = time.perf_counter()
             for _ in range(steps):
-                torch.cuda.current_stream().wait_stream(side)
-                cur = nxt
-                forward_on(cur)                                      # enqueue the step ...
-                nxt = build()                                        # ... and build the next batch under it
+                pipelined_step()
             torch.cuda.synchronize()
             incl_ms = 1e3 * D.max(time.perf_counter() - t0) / steps
+            keep.clear()
         if want_roofline and rank == 0:
             timer.enabled = True
             for i in range(min(steps, 8)):

@@ -216,7 +216,9 @@ class BatchData(object):
         batch vector, the distinct-molecule graph + row map and (pair batches) the cross-graph attention's size-class pair
         order -- NOW, on the current stream.  Each is otherwise built on first use inside the forward, where its
         host-to-device copy makes the host wait for the kernels already enqueued: a loop that builds batch k + 1 on a side
-        stream while batch k runs calls this at build time.  -> self"""
+        stream while batch k runs calls this at build time (and, as with any tensor allocated on one stream and read on
+        another, keeps the batch alive until the stream that READS it is done with it -- or ``record_stream``s its
+        tensors: bench.py's ``pipelined_step``).  -> self"""
         m = self.merge_data['merge']
         m.csr()
         m.segments()

@@ -130,3 +130,30 @@ def test_linear_bf16x6_odd_widths(device, M, N, K):
         pytest.skip("shape stays on the f32 kernels")
     got = ops.linear(xd, wd, transform="bf16x6")
     assert max_err(got, x.double() @ w.double()) < TOL
+
+
+@pytest.mark.parametrize("n_mols,K,N", [(1, 4, 256), (3, 252, 256), (5, 36, 256), (9, 160, 256), (9, 224, 256), (2, 256, 256),
+                                         (3, 68, 128)])
+def test_gin_layer_f16x3_odd_shapes_and_unaligned_output(device, n_mols, K, N):
+    """the d = 256 layer kernel (64-row tiles, two workgroups per CU) off its fast paths: fewer rows than one tile, K that is
+    not a multiple of 64 (zero-padded steps of the weight stream: K = 4, 36, 160, 224, 252), and an output slice whose
+    leading dimension / base address rule out 16-byte stores (per-element stores with the row predicate)"""
+    ds = blgnn.make_synthetic(n_mols, 10, seed=5 + K, device="cpu")
+    merged = ds.molecules.merge(ds.molecules.gids)["merge"]
+    ei, n = merged.edge_index, merged.x.shape[0]
+    g = torch.Generator().manual_seed(K + N)
+    x = torch.randn(n, K, generator=g)
+    w1, b1 = torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g) * 0.1
+    w2, b2 = torch.randn(N, N, generator=g) / N ** 0.5, torch.randn(N, generator=g) * 0.1
+    D = lambda t: t.double()
+    ref = oracle.apply_act(oracle.gin_conv(D(x), ei, D(w1), D(b1), D(w2), D(b2), "relu", eps=0.5), "relu")
+    dv = lambda t: t.to(device)
+    csr = ops.csr_from_edge_index(dv(ei), n)
+    assert ops.gin_layer_h3_supported(csr, dv(x), K, N)
+    w1p, w2p = ops.pack_weight_h3(dv(w1.t().contiguous())), ops.pack_weight_h3(dv(w2.t().contiguous()))
+    got = ops.gin_layer_h3(csr, dv(x), w1p, dv(b1), w2p, dv(b2), N, eps=0.5, act="relu")
+    assert max_err(got, ref) < TOL
+    wide = torch.full((n, N + 3), -3.0, device=device)
+    odd = ops.gin_layer_h3(csr, dv(x), w1p, dv(b1), w2p, dv(b2), N, eps=0.5, act="relu", out=wide[:, 1:1 + N])
+    assert torch.equal(odd, got)
+    assert float((wide[:, :1] + 3.0).abs().max()) == 0.0 and float((wide[:, 1 + N:] + 3.0).abs().max()) == 0.0
