@@ -439,7 +439,7 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
     saved_agg = ops.gat_aggregate
 
     def agg_work(csr, h, sc, stats, bias, *a, **kw):
-        rows = kw.get("rows", a[8] if len(a) > 8 else None)
+        rows = kw.get("rows", a[8] if len(a) > 8 else None)      # (positional after bias: group .. accumulate, rows, packed)
         n, dd = h.shape
         frac = 1.0 if rows is None else float(rows.numel()) / max(n, 1)
         gathered = 4.0 * dd * (csr.nnz + n) * frac

@@ -50,9 +50,9 @@ SIGNATURES = {
     "blgnn_gcn_deg_inv_sqrt": [_p, _p, _p, _i32, _p, _p],
     "blgnn_gcn_aggregate": [_p, _p, _i64, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _p, _i32, _p, _p, _p, _i32, _p],
     "blgnn_gat_scores": [_p, _i64, _p, _i32, _i32, _p, _p, _p],
-    "blgnn_gat_softmax_stats": [_p, _p, _i64, _p, _p, _i32, _i32, _f32, _p, _p, _p],
+    "blgnn_gat_softmax_stats": [_p, _p, _i64, _p, _p, _i32, _i32, _f32, _p, _p, _p, _p],
     "blgnn_gat_aggregate": [_p, _p, _i64, _p, _i64, _p, _p, _p, _p, _i32, _f32, _p, _i64, _i32, _i32,
-                            _p, _i32, _p, _p, _p, _i32, _p, _i32, _p],
+                            _p, _i32, _p, _p, _p, _i32, _p, _i32, _p, _p],
     "blgnn_edge_relu_sum": [_p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _p, _i64, _p, _i64, _p],
     "blgnn_row_degree": [_p, _i32, _p, _p],
     "blgnn_segment_reduce": [_p, _i32, _p, _i64, _i32, _i32, _p, _i64, _p, _p],

@@ -608,15 +608,20 @@ def gat_from_transform(csr, h, sc, bias, group="src", slope=0.2, act="identity",
         raise ValueError("blgnn: scores must be a contiguous [2, n] tensor")
     stats = torch.empty((2, n), dtype=torch.float32, device=h.device)
     s_dst, s_src, mx, den = sc[0].data_ptr(), sc[1].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr()
+    # SRC grouping on a large graph: (s_src, max, denominator) of a node also packed into one 16-byte word, so that the
+    # aggregation gathers one sector per edge instead of three
+    packed = torch.empty((n, 4), dtype=torch.float32, device=h.device) if (group == "src" and n >= 16384) else None
     call("blgnn_gat_softmax_stats", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, s_dst, s_src, n,
-         GAT_GROUP[group], float(slope), mx, den, _stream())
-    return gat_aggregate(csr, h, sc, stats, bias, group, slope, act, act_param, bn_scale, bn_shift, out, accumulate, rows)
+         GAT_GROUP[group], float(slope), mx, den, None if packed is None else packed.data_ptr(), _stream())
+    return gat_aggregate(csr, h, sc, stats, bias, group, slope, act, act_param, bn_scale, bn_shift, out, accumulate, rows,
+                         packed)
 
 
 def gat_aggregate(csr, h, sc, stats, bias, group="src", slope=0.2, act="identity", act_param=None,
-                  bn_scale=None, bn_shift=None, out=None, accumulate=False, rows=None):
+                  bn_scale=None, bn_shift=None, out=None, accumulate=False, rows=None, packed=None):
     """The weighted neighbour sum of GATConv (blgnn_gat_aggregate: the interaction-level gather) on a transformed table
-    with its scores ``sc`` [2, n] and softmax statistics ``stats`` [2, n] (max, denominator per group)."""
+    with its scores ``sc`` [2, n] and softmax statistics ``stats`` [2, n] (max, denominator per group; ``packed`` [n, 4]:
+    the same per node in one word, as blgnn_gat_softmax_stats writes it)."""
     n, d = h.shape
     hp, ldh = _mat(h, "h")
     y = _out(out, n, d, h)
@@ -625,7 +630,7 @@ def gat_aggregate(csr, h, sc, stats, bias, group="src", slope=0.2, act="identity
          sc[1].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), GAT_GROUP[group], float(slope), yp, ldy, n, d,
          _vec(bias, "bias"), _act(act), _vec(act_param, "act_param"), _vec(bn_scale, "bn_scale"),
          _vec(bn_shift, "bn_shift"), int(bool(accumulate)), _vec(rows, "rows", torch.int64),
-         0 if rows is None else rows.numel(), _stream())
+         0 if rows is None else rows.numel(), None if packed is None else packed.data_ptr(), _stream())
     return y
 
 
@@ -942,12 +947,12 @@ def gat_forward_saved(csr, x, weight, att, bias, group="src", slope=0.2, act="id
     s = _stream()
     hp, ldh = _mat(h, "h")
     call("blgnn_gat_softmax_stats", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, sc[0].data_ptr(), sc[1].data_ptr(), n,
-         GAT_GROUP[group], float(slope), stats[0].data_ptr(), stats[1].data_ptr(), s)
+         GAT_GROUP[group], float(slope), stats[0].data_ptr(), stats[1].data_ptr(), None, s)
     y = _out(out, n, d, h)
     yp, ldy = _mat(y, "out")
     call("blgnn_gat_aggregate", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.nnz, hp, ldh, sc[0].data_ptr(),
          sc[1].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), GAT_GROUP[group], float(slope), yp, ldy, n, d,
-         _vec(bias, "bias"), _act(act), None, None, None, int(bool(accumulate)), None, 0, s)
+         _vec(bias, "bias"), _act(act), None, None, None, int(bool(accumulate)), None, 0, None, s)
     return y, h, sc, stats
 
 

@@ -36,6 +36,7 @@ struct GatherArgs {
     const float *dis;    // GCN
     // GAT
     const float *s_dst, *s_src, *mx, *den;
+    const float4 *packed;  // optional [n]: (s_src, mx, den, -) of every node in one 16-byte word (SRC grouping: one gather per edge instead of three)
     int32_t group;
     float slope;
     // RELU
@@ -75,6 +76,10 @@ struct EdgeCtx {
         if (MODE == MODE_SUM) return A.self_coef;
         if (MODE == MODE_GCN) return a * a;
         if (MODE == MODE_GAT) {
+            if (A.packed) {
+                const float4 t = A.packed[row];
+                return expf(lrelu(a + t.x, A.slope) - t.y) / (t.z + 1e-16f);
+            }
             float e = lrelu(a + A.s_src[row], A.slope);
             return expf(e - A.mx[row]) / (A.den[row] + 1e-16f);
         }
@@ -92,6 +97,10 @@ struct EdgeCtx {
         }
         if (MODE == MODE_GAT) {
             if (j == row) return 0.f;
+            if (A.packed && A.group != BLGNN_GAT_GROUP_DST) {
+                const float4 t = A.packed[j];                    // same arithmetic, one gather
+                return expf(lrelu(a + t.x, A.slope) - t.y) / (t.z + 1e-16f);
+            }
             float ev = lrelu(a + A.s_src[j], A.slope);
             if (A.group == BLGNN_GAT_GROUP_DST) return expf(ev - b) * c;
             return expf(ev - A.mx[j]) / (A.den[j] + 1e-16f);
@@ -655,7 +664,7 @@ constexpr int HUB_BLOCKS = 128;
 template <int MODE, int LG, int CH>
 __global__ void __launch_bounds__(256) k_gather_wave(const GatherArgs A) {
     constexpr int S = WAVE / LG;                 // lane groups = edge slots of the wavefront
-    constexpr int U = CH <= 1 ? 8 : (CH <= 2 ? 4 : 2);   // neighbour rows in flight per slot
+    constexpr int U = CH <= 1 ? 12 : (CH <= 2 ? 4 : 2);   // neighbour rows in flight per slot (8: 381 us, 12: 357, 16: 376 at configs[3])
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
     const int sub = lane / LG, l = lane % LG;
     const int d4 = A.d >> 2;
@@ -977,7 +986,7 @@ template <int LG>
 __global__ void __launch_bounds__(256)
 k_gat_stats(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
             const float *__restrict__ s_dst, const float *__restrict__ s_src, int32_t n,
-            int32_t group, float slope, float *__restrict__ mx, float *__restrict__ den) {
+            int32_t group, float slope, float *__restrict__ mx, float *__restrict__ den, float4 *__restrict__ packed) {
     const int l = threadIdx.x % LG;
     const int g0 = (blockIdx.x * blockDim.x + threadIdx.x) / LG;
     const int step = gridDim.x * blockDim.x / LG;
@@ -1003,7 +1012,10 @@ k_gat_stats(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
             sum += expf(a - m);
         }
         sum = group_sum(sum, LG);
-        if (l == 0) { mx[g] = m; den[g] = sum; }
+        if (l == 0) {
+            mx[g] = m; den[g] = sum;
+            if (packed) packed[g] = make_float4(ss, m, sum, 0.f);
+        }
     }
 }
 
@@ -1111,19 +1123,21 @@ extern "C" int blgnn_gat_scores(const float *h, int64_t ldh, const float *att, i
 
 extern "C" int blgnn_gat_softmax_stats(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                                        const float *s_dst, const float *s_src, int32_t n,
-                                       int32_t group, float slope, float *mx, float *den,
+                                       int32_t group, float slope, float *mx, float *den, float *stats_packed,
                                        void *stream) {
     if (int rc = check_csr(rowptr, col, n, nnz, "gat_softmax_stats")) return rc;
     BLGNN_CHECK_ARG(group == BLGNN_GAT_GROUP_SRC || group == BLGNN_GAT_GROUP_DST,
                     "gat_softmax_stats: bad group");
     BLGNN_CHECK_ARG(n == 0 || (s_dst && s_src && mx && den), "gat_softmax_stats: null pointer");
+    BLGNN_CHECK_ARG(aligned16(stats_packed), "gat_softmax_stats: stats_packed must be 16-byte aligned");
     if (n == 0) return BLGNN_OK;
+    float4 *packed = reinterpret_cast<float4 *>(stats_packed);
     if (nnz >= WIDE_MEAN_DEGREE * (int64_t)n)      // high-degree graph: a whole wavefront per node
         hipLaunchKernelGGL(k_gat_stats<64>, dim3(grid1d(n, 4)), dim3(256), 0, (hipStream_t)stream, rowptr,
-                           col, s_dst, s_src, n, group, slope, mx, den);
+                           col, s_dst, s_src, n, group, slope, mx, den, packed);
     else
         hipLaunchKernelGGL(k_gat_stats<16>, dim3(grid1d(n, 16)), dim3(256), 0, (hipStream_t)stream, rowptr,
-                           col, s_dst, s_src, n, group, slope, mx, den);
+                           col, s_dst, s_src, n, group, slope, mx, den, packed);
     return launch_status("gat_softmax_stats");
 }
 
@@ -1133,8 +1147,9 @@ extern "C" int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col, in
                                    float *y, int64_t ldy, int32_t n, int32_t d, const float *bias,
                                    int32_t act, const float *act_param, const float *bn_scale,
                                    const float *bn_shift, int32_t accumulate, const int64_t *rows, int32_t num_rows,
-                                   void *stream) {
+                                   const float *stats_packed, void *stream) {
     if (int rc = check_csr(rowptr, col, n, nnz, "gat_aggregate")) return rc;
+    BLGNN_CHECK_ARG(aligned16(stats_packed), "gat_aggregate: stats_packed must be 16-byte aligned");
     BLGNN_CHECK_ARG(!rows || num_rows >= 0, "gat_aggregate: negative row count");
     BLGNN_CHECK_ARG(group == BLGNN_GAT_GROUP_SRC || group == BLGNN_GAT_GROUP_DST,
                     "gat_aggregate: bad group");
@@ -1149,6 +1164,7 @@ extern "C" int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col, in
     A.epi = Epilogue{bias, act_param, bn_scale, bn_shift, act};
     A.accumulate = accumulate;
     A.row_list = rows; A.n_list = rows ? num_rows : 0;
+    A.packed = reinterpret_cast<const float4 *>(stats_packed);
     return dispatch<MODE_GAT>(A, nnz, true, (hipStream_t)stream, "gat_aggregate");
 }
 

@@ -260,11 +260,13 @@ int blgnn_gat_transform(const float *x, int64_t ldx, const float *w, int64_t ldw
  * a_e = leaky_relu(s_dst[target] + s_src[source], slope) over the edges of the
  * group plus the appended self loop; existing self loops are dropped.
  * (rowptr,col) must be the CSR keyed by the grouping side; for the symmetric
- * graphs of this path (model/layers_util.py:133) it is the same CSR either way. */
+ * graphs of this path (model/layers_util.py:133) it is the same CSR either way.
+ * stats_packed (optional, [n][4] floats, 16-byte aligned): additionally (s_src[g], mx[g], den[g], 0) per node in one
+ * 16-byte word -- what blgnn_gat_aggregate gathers per edge under SRC grouping (one sector per edge instead of three). */
 int blgnn_gat_softmax_stats(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                             const float *s_dst, const float *s_src, int32_t n,
                             int32_t group, float slope, float *mx, float *den,
-                            void *stream);
+                            float *stats_packed, void *stream);
 /* Step 3: y[i] (+)= epi( sum_{j in N(i) u {i}} alpha_ij h_j + bias ),
  * alpha_ij = exp(a_ij - mx[g]) / (den[g] + 1e-16), g = j (SRC) or i (DST).
  * accumulate != 0 adds into y (NodeModelAggrByEdge: model/layers_meta.py:74-79);
@@ -272,7 +274,8 @@ int blgnn_gat_softmax_stats(const int32_t *rowptr, const int32_t *col, int64_t n
  * rows / num_rows (optional): compute only the target rows rows[0 .. num_rows) (int64 device array, duplicates
  * allowed) and leave every other row of y untouched -- the LAST interaction-level layer feeds only the rows the pair
  * scorer reads (model/layers_link_pred.py:56-61), so a rank of a sharded job need not compute the others.  Honoured
- * by the high-degree (one workgroup per row) kernel; low-degree graphs compute every row. */
+ * by the high-degree kernels (one workgroup per row; one wavefront per row from 16 384 rows on); low-degree graphs
+ * compute every row.  stats_packed (optional): the packed statistics blgnn_gat_softmax_stats wrote (same values). */
 int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                         const float *h, int64_t ldh, const float *s_dst,
                         const float *s_src, const float *mx, const float *den,
@@ -280,7 +283,7 @@ int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                         int32_t n, int32_t d, const float *bias, int32_t act,
                         const float *act_param, const float *bn_scale,
                         const float *bn_shift, int32_t accumulate, const int64_t *rows, int32_t num_rows,
-                        void *stream);
+                        const float *stats_packed, void *stream);
 
 /* GMN message: model/layers_gmn.py:38-42 restructured:
  * y[i] = sum_{e: key_e = i} relu(p[i] + q[nbr_e])  (self loops kept).
