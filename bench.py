@@ -528,7 +528,7 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
            "config": {"workload": cfg["name"], "drugs": n_drugs, "atoms_per_gpu": Nn, "mol_edges_per_gpu": nnz,
                       "interaction_pairs": int(len(ds.pair_gids)), "d": d, "pairs_per_step_per_gpu": batch,
                       "pairs_per_step": pairs_per_step, "fresh_batch_every_step": True,
-                      "hip_graph": bool(engine.use_graph), "two_stream_overlap": bool(engine.overlap),
+                      "hip_graph": bool(engine.use_graph), "two_stream_overlap": bool(engine.overlap and not engine.serialized),
                       "readout_with_upper": bool(engine.readout_with_upper),
                       "fused_readout": bool(getattr(flags, "fuse_readout", False)) and engine.fused is None,
                       "lower_cus_per_xcd": engine.lower_cus_per_xcd, "fused_lower_stack": engine.fused is not None,

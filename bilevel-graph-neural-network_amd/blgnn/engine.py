@@ -134,7 +134,7 @@ class BiLevelEngine(object):
 
     def __init__(self, model, lower_batch, upper_batches, graph, sharded=None, world_size=1,
                  use_graph=True, overlap=True, fuse_lower=None, readout_with_upper=None, lower_cus_per_xcd=None,
-                 exchange_transformed=None, prune_last=None, parity_streams=False):
+                 exchange_transformed=None, prune_last=None, parity_streams=False, serialize=None):
         from .config import FLAGS
         k = FLAGS.last_lower_lyr_num
         self.model = model
@@ -255,7 +255,15 @@ class BiLevelEngine(object):
         # ``step()`` (diagnostic: tests/test_gpu_model.py checks that the parities' graphs touch no common buffer that
         # either writes -- by default both parities' sweeps share stream L and both interaction passes stream U, which
         # would hide such a buffer).  Not a speed-up: measured 0.34 vs 0.20 ms per step at configs[1] in round 3.
+        # ``serialize``: sweep and interaction pass of consecutive steps on ONE stream (still double-buffered, still
+        # asynchronous to the host, the id copies still on their own stream).  None = decided at capture time from the two
+        # graphs' own durations: when the sweep is >= 4x the interaction pass there is little to gain from running them side
+        # by side (configs[3] at N = 1: 20.7 + 2.1 ms in a row against 22.4 overlapped) and something to lose -- beside the
+        # sweep's tens of thousands of workgroups the short pass's kernels can starve until it outlasts the sweep and stalls
+        # the next-but-one (22 -> 27-35 ms in episodes; profiles/r04_cfg3_emulated_ranks.txt).
+        self.serialize = serialize
         self.parity_streams = bool(parity_streams and self.overlap)
+        self.serialized = False
         self._sl = [self.stream_l, torch.cuda.Stream(device=dev) if self.parity_streams else self.stream_l]
         self._su = [self.stream_u, torch.cuda.Stream(device=dev) if self.parity_streams else self.stream_u]
         self.ev_lower = [None] * self.parities
@@ -435,6 +443,23 @@ class BiLevelEngine(object):
                 self.g_upper[p] = g
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self.overlap and not self.parity_streams and self._masked is None:
+            ser = self.serialize
+            if ser is None:
+                ser = False
+                if self.world <= 1:                      # (with ranks every rank must decide alike: left to the caller)
+                    t = []
+                    for gr in (self.g_lower[0], self.g_upper[0]):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        gr.replay()
+                        e0.record()
+                        gr.replay()
+                        e1.record()
+                        torch.cuda.synchronize()
+                        t.append(e0.elapsed_time(e1))
+                    ser = t[0] >= 4.0 * t[1] and t[0] >= 2.0     # (ms; sweeps below 2 ms keep the overlap they were tuned with)
+            self.serialized = bool(ser)
+            self._su = [self._sl[0], self._sl[1]] if self.serialized else [self.stream_u, self.stream_u]
 
     # ---- steady state ---------------------------------------------------------------------------
     def step(self, which):
