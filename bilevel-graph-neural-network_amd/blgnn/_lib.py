@@ -84,6 +84,7 @@ SIGNATURES = {
     "blgnn_bn_apply": [_p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p],
     "blgnn_bn_backward": [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i32, _i32, _i64, _p, _i64, _p],
     "blgnn_act_backward": [_p, _i64, _p, _i64, _i32, _p, _i32, _i32, _p, _i64, _p],
+    "blgnn_act_forward": [_p, _i64, _i32, _p, _i32, _i32, _p, _i64, _p],
     "blgnn_transpose": [_p, _i64, _i32, _i32, _p, _i64, _p],
     "blgnn_segment_broadcast": [_p, _i32, _p, _i64, _p, _i32, _i32, _p, _i64, _i32, _p],
     "blgnn_l2_normalize_backward": [_p, _i64, _p, _i64, _i32, _i32, _f32, _p, _i64, _p],

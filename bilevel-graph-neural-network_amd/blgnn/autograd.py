@@ -25,7 +25,7 @@ import torch
 
 from . import ops
 
-__all__ = ["linear", "gat_conv", "gcn_conv", "multi_edge_gat", "edge_relu_sum", "gmn_match", "spmm_sum", "batch_norm_train", "segment_reduce_multi", "l2_normalize", "pair_gather",
+__all__ = ["linear", "prelu", "gat_conv", "gcn_conv", "multi_edge_gat", "edge_relu_sum", "gmn_match", "spmm_sum", "batch_norm_train", "segment_reduce_multi", "l2_normalize", "pair_gather",
            "training_active", "set_batch_norm_sync"]
 
 
@@ -36,7 +36,39 @@ def training_active(module):
 
 def _check_act(act):
     if act == "prelu":
-        raise NotImplementedError("blgnn: PReLU slopes are not trained on this path (relu / identity / sigmoid / tanh)")
+        raise ValueError("blgnn: a trained PReLU is its own autograd node (autograd.prelu) behind an identity-activation layer")
+
+
+class _PRelu(torch.autograd.Function):
+    """y = PReLU(z), slope [1] or [N] (create_act('prelu', out_dim): model/layers_util.py:63-64, the activation of a
+    NodeEmbedding layer -- model/layers.py:24,26,34,55; inside the GIN MLP the SAME module, so its slope gradient is the
+    sum over both uses, which autograd accumulates).  The pre-activation is kept: the derivative tests ITS sign, so the
+    slopes may take any sign while training."""
+
+    @staticmethod
+    def forward(ctx, z, slope):
+        z, slope = z.detach(), slope.detach()
+        per_col = slope.expand(z.shape[1]).contiguous()
+        y = ops.act_forward(z, "prelu", per_col)
+        ctx.single = slope.numel() == 1 and z.shape[1] != 1
+        ctx.save_for_backward(z, per_col)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, per_col = ctx.saved_tensors
+        dy = dy.contiguous()
+        dz = ops.act_backward(dy, z, "prelu", per_col) if ctx.needs_input_grad[0] else None
+        ds = None
+        if ctx.needs_input_grad[1]:
+            ds = ops.col_reduce(dy, "dot_neg", b=z)                               # sum_m dy * min(z, 0) per channel
+            if ctx.single:
+                ds = ops.col_reduce(ds.view(-1, 1), "sum")                        # one shared slope: nn.PReLU()
+        return dz, ds
+
+
+def prelu(z, slope):
+    return _PRelu.apply(z, slope)
 
 
 class _Linear(torch.autograd.Function):

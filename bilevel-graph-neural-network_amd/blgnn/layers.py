@@ -322,11 +322,18 @@ class NodeEmbedding(nn.Module):
             raise NotImplementedError("blgnn: train mode does not write into a caller-provided slice")
         csr = self._graph(batch_data).csr()
         act = act_name(self.act)
+        # a PReLU trains its slopes: the layers run with the identity and the activation is its own node behind them
+        # (it keeps the pre-activation); in the GIN layer the reference puts the SAME module between the two Linears
+        # and behind the conv (model/layers.py:26-31,55), so both uses feed one slope gradient
+        trained = self.act.weight if act == "prelu" else None
+        if trained is not None:
+            act = "identity"
+        after = (lambda t: ag.prelu(t, trained)) if trained is not None else (lambda t: t)
         if self.type == 'gin':
             lin1, lin2 = self.conv.nn[0], self.conv.nn[2]
             # (eps is a buffer, not trained: read once per version, no device -> host copy per step)
             agg = ag.spmm_sum(ins, csr, 1.0 + self._cache.get("eps", lambda e: float(e[0]), self.conv.eps))
-            h = ag.linear(agg, lin1.weight, lin1.bias, act)
+            h = after(ag.linear(agg, lin1.weight, lin1.bias, act))
             x = ag.linear(h, lin2.weight, lin2.bias, act)           # conv, then the layer's act (layers.py:55)
         elif self.type == 'gat':
             x = ag.gat_conv(ins, self.conv.weight, self.conv.att, self.conv.bias, csr,
@@ -335,6 +342,7 @@ class NodeEmbedding(nn.Module):
             if getattr(batch_data.merge_data['merge'], "edge_attr", None) is not None:
                 raise NotImplementedError("blgnn: GCN layers train without edge weights (none of the shipped configs has any)")
             x = ag.gcn_conv(ins, self.conv.weight, self.conv.bias, csr, act=act)
+        x = after(x)
         if self.bn:
             x = ag.batch_norm_train(x, self.bn)
         model.store_layer_output(self, x)

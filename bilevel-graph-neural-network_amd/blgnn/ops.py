@@ -840,12 +840,12 @@ def expand_rows_sp(src, row_map, out):
 
 # ---- backward pass / train mode (include/blgnn.h "backward pass" block) -------------------------------------
 
-_COL_MODES = {"sum": 0, "dot": 1, "sqdev": 2, "dot_norm": 3}
+_COL_MODES = {"sum": 0, "dot": 1, "sqdev": 2, "dot_norm": 3, "dot_neg": 4}
 
 
 def col_reduce(a, mode="sum", b=None, mean=None, rstd=None, scale=1.0, out=None):
     """Deterministic column reduction over all rows: sum a | sum a*b | sum (a - mean)^2 |
-    sum a * (b - mean) * rstd, times ``scale``."""
+    sum a * (b - mean) * rstd | sum a * min(b, 0), times ``scale``."""
     ap, lda = _mat(a, "a")
     M, N = a.shape
     bp, ldb = (None, 0) if b is None else _mat(b, "b")
@@ -886,6 +886,15 @@ def bn_backward(dy, x, mean, rstd, gamma, dgamma, dbeta, out=None, count=None):
          _vec(gamma, "gamma"), _vec(dgamma, "dgamma", optional=False), _vec(dbeta, "dbeta", optional=False),
          x.shape[0], x.shape[1], int(round(count)) if count is not None else x.shape[0], dxp, lddx, _stream())
     return dx
+
+
+def act_forward(x, act, slope=None, out=None):
+    """y = act(x) as its own launch (per-column PReLU slopes): the training path keeps the pre-activation."""
+    xp, ldx = _mat(x, "x")
+    y = _out(out, x.shape[0], x.shape[1], x)
+    yp, ldy = _mat(y, "out")
+    call("blgnn_act_forward", xp, ldx, _act(act), _vec(slope, "slope"), x.shape[0], x.shape[1], yp, ldy, _stream())
+    return y
 
 
 def act_backward(dy, y, act, slope=None, out=None):

@@ -24,9 +24,10 @@ static inline int cr_rows(int M) {
     int r = ((M + 511) / 512 + 31) / 32 * 32;
     return r < 64 ? 64 : (r > CR_ROWS ? CR_ROWS : r);
 }
-enum { COL_SUM = 0, COL_DOT = 1, COL_SQDEV = 2, COL_DOT_NORM = 3 };
+enum { COL_SUM = 0, COL_DOT = 1, COL_SQDEV = 2, COL_DOT_NORM = 3, COL_DOT_NEG = 4 };
 
-// partial[chunk][c] = sum over the chunk's rows of  a  |  a * b  |  (a - mean[c])^2  |  a * (b - mean[c]) * rstd[c]
+// partial[chunk][c] = sum over the chunk's rows of  a  |  a * b  |  (a - mean[c])^2  |  a * (b - mean[c]) * rstd[c]  |
+// a * min(b, 0)  (the slope gradient of a per-channel PReLU: a = dy, b = the pre-activation)
 template <int MODE>
 __global__ void __launch_bounds__(256) k_col_partial(const float *__restrict__ a, int64_t lda,
                                                      const float *__restrict__ b, int64_t ldb,
@@ -47,6 +48,7 @@ __global__ void __launch_bounds__(256) k_col_partial(const float *__restrict__ a
             if (MODE == COL_SUM) s += v;
             else if (MODE == COL_DOT) s = fmaf(v, b[(int64_t)r * ldb + c], s);
             else if (MODE == COL_DOT_NORM) s = fmaf(v, (b[(int64_t)r * ldb + c] - mu) * rs, s);
+            else if (MODE == COL_DOT_NEG) s = fmaf(v, fminf(b[(int64_t)r * ldb + c], 0.f), s);
             else { const float dlt = v - mu; s = fmaf(dlt, dlt, s); }
         }
     }
@@ -120,8 +122,10 @@ __global__ void k_bn_backward(const float *__restrict__ dy, int64_t lddy, const 
                                 (dy[(int64_t)r * lddy + c] - dbeta[c] * inv_m - xh * dgamma[c] * inv_m);
 }
 
-// dx = dy * act'(.) from the activation's OUTPUT y: relu y > 0, prelu (y > 0 ? 1 : slope; slope > 0 assumed for
-// the sign test on y), sigmoid y (1 - y), tanh 1 - y^2, identity 1.  dslope (PReLU, optional) is not produced here.
+// dx = dy * act'(.) from the activation's OUTPUT y: relu y > 0, sigmoid y (1 - y), tanh 1 - y^2, identity 1.
+// PReLU (v > 0 ? 1 : slope[c]) tests the sign of what the caller passes: the PRE-activation for trained slopes (any sign
+// of the slope; blgnn/autograd.py keeps it), the output only where slope > 0 is known.  The slope gradient is
+// blgnn_col_reduce's a * min(b, 0) mode.
 __global__ void k_act_backward(const float *__restrict__ dy, int64_t lddy, const float *__restrict__ y, int64_t ldy,
                                int act, const float *__restrict__ slope, int M, int N, float *__restrict__ dx,
                                int64_t lddx) {
@@ -135,6 +139,15 @@ __global__ void k_act_backward(const float *__restrict__ dy, int64_t lddy, const
     else if (act == BLGNN_ACT_SIGMOID) d = v * (1.f - v);
     else if (act == BLGNN_ACT_TANH) d = 1.f - v * v;
     dx[(int64_t)r * lddx + c] = g * d;
+}
+
+// y = act(x) with a per-channel PReLU slope: the activation as its own step where the backward needs the pre-activation
+__global__ void k_act_forward(const float *__restrict__ x, int64_t ldx, int act, const float *__restrict__ slope, int M,
+                              int N, float *__restrict__ y, int64_t ldy) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)M * N) return;
+    const int r = (int)(idx / N), c = (int)(idx % N);
+    y[(int64_t)r * ldy + c] = apply_act(x[(int64_t)r * ldx + c], act, slope ? slope[c] : 0.f);
 }
 
 // y[N, M] = x[M, N]^T through a padded 32 x 32 LDS tile
@@ -355,9 +368,9 @@ extern "C" int64_t blgnn_col_reduce_scratch_elems(int32_t M, int32_t N) {
 extern "C" int blgnn_col_reduce(const float *a, int64_t lda, const float *b, int64_t ldb, const float *mean,
                                 const float *rstd, int32_t M, int32_t N, int32_t mode, float scale, float *scratch,
                                 float *out, void *stream) {
-    BLGNN_CHECK_ARG(M >= 0 && N > 0 && mode >= COL_SUM && mode <= COL_DOT_NORM, "col_reduce: bad sizes / mode");
+    BLGNN_CHECK_ARG(M >= 0 && N > 0 && mode >= COL_SUM && mode <= COL_DOT_NEG, "col_reduce: bad sizes / mode");
     BLGNN_CHECK_ARG(a && out && scratch && lda >= N, "col_reduce: null pointer / leading dimension");
-    BLGNN_CHECK_ARG((mode != COL_DOT && mode != COL_DOT_NORM) || (b && ldb >= N), "col_reduce: dot modes need b");
+    BLGNN_CHECK_ARG((mode != COL_DOT && mode != COL_DOT_NORM && mode != COL_DOT_NEG) || (b && ldb >= N), "col_reduce: dot modes need b");
     BLGNN_CHECK_ARG((mode != COL_SQDEV && mode != COL_DOT_NORM) || mean, "col_reduce: this mode needs the column means");
     BLGNN_CHECK_ARG(mode != COL_DOT_NORM || rstd, "col_reduce: dot_norm mode needs rstd");
     hipStream_t s = (hipStream_t)stream;
@@ -368,6 +381,7 @@ extern "C" int blgnn_col_reduce(const float *a, int64_t lda, const float *b, int
         if (mode == COL_SUM) hipLaunchKernelGGL(k_col_partial<COL_SUM>, grid, dim3(256), 0, s, a, lda, b, ldb, mean, rstd, M, N, rows, scratch);
         else if (mode == COL_DOT) hipLaunchKernelGGL(k_col_partial<COL_DOT>, grid, dim3(256), 0, s, a, lda, b, ldb, mean, rstd, M, N, rows, scratch);
         else if (mode == COL_SQDEV) hipLaunchKernelGGL(k_col_partial<COL_SQDEV>, grid, dim3(256), 0, s, a, lda, b, ldb, mean, rstd, M, N, rows, scratch);
+        else if (mode == COL_DOT_NEG) hipLaunchKernelGGL(k_col_partial<COL_DOT_NEG>, grid, dim3(256), 0, s, a, lda, b, ldb, mean, rstd, M, N, rows, scratch);
         else hipLaunchKernelGGL(k_col_partial<COL_DOT_NORM>, grid, dim3(256), 0, s, a, lda, b, ldb, mean, rstd, M, N, rows, scratch);
     }
     hipLaunchKernelGGL(k_col_final, dim3((N + 63) / 64), dim3(256), 0, s, scratch, chunks, N, scale, out);
@@ -439,6 +453,18 @@ extern "C" int blgnn_act_backward(const float *dy, int64_t lddy, const float *y,
     hipLaunchKernelGGL(k_act_backward, dim3(grid_for((int64_t)M * N, 256)), dim3(256), 0, (hipStream_t)stream, dy, lddy, y, ldy,
                        act, slope, M, N, dx, lddx);
     return launch_status("act_backward");
+}
+
+extern "C" int blgnn_act_forward(const float *x, int64_t ldx, int32_t act, const float *slope, int32_t M, int32_t N,
+                                 float *y, int64_t ldy, void *stream) {
+    BLGNN_CHECK_ARG(M >= 0 && N > 0 && ldx >= N && ldy >= N, "act_forward: bad sizes");
+    BLGNN_CHECK_ARG(act >= 0 && act <= BLGNN_ACT_TANH, "act_forward: bad activation id");
+    BLGNN_CHECK_ARG(act != BLGNN_ACT_PRELU || slope, "act_forward: PReLU needs its slopes");
+    if (M == 0) return BLGNN_OK;
+    BLGNN_CHECK_ARG(x && y, "act_forward: null pointer");
+    hipLaunchKernelGGL(k_act_forward, dim3(grid_for((int64_t)M * N, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, act,
+                       slope, M, N, y, ldy);
+    return launch_status("act_forward");
 }
 
 extern "C" int blgnn_transpose(const float *x, int64_t ldx, int32_t M, int32_t N, float *y, int64_t ldy, void *stream) {

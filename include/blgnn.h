@@ -499,6 +499,8 @@ int blgnn_expand_rows(const void *src, int64_t ld_src, const int32_t *row_map, i
 #define BLGNN_COL_DOT   1   /* out[c] = scale * sum_m a[m, c] * b[m, c]             */
 #define BLGNN_COL_SQDEV 2   /* out[c] = scale * sum_m (a[m, c] - mean[c])^2         */
 #define BLGNN_COL_DOT_NORM 3 /* out[c] = scale * sum_m a[m, c] * (b[m, c] - mean[c]) * rstd[c] */
+#define BLGNN_COL_DOT_NEG 4 /* out[c] = scale * sum_m a[m, c] * min(b[m, c], 0): the slope gradient of nn.PReLU(out_dim)
+                             * (model/layers_util.py:63-64; model/layers.py:24,26,34), a = dy, b = pre-activation */
 
 /* Column reduction over all M rows: bias gradients (sum of dY), train-mode BatchNorm1d statistics
  * (model/layers.py:39-40: mean = COL_SUM / M, biased var = COL_SQDEV / M, two-pass like torch) and its
@@ -539,11 +541,18 @@ int blgnn_bn_backward(const float *dy, int64_t lddy, const float *x, int64_t ldx
                       const float *dbeta, int32_t M, int32_t N, int64_t count, float *dx,
                       int64_t lddx, void *stream);
 
-/* dx = dy * act'(.) evaluated from the activation's OUTPUT y (relu / prelu with positive slopes /
- * sigmoid / tanh / identity); dx may alias dy. */
+/* dx = dy * act'(.) evaluated from the activation's OUTPUT y (relu / sigmoid / tanh / identity); for PReLU the
+ * derivative (v > 0 ? 1 : slope[c]) takes the sign of what is passed as y -- the pre-activation when slopes are
+ * trained (any sign of the slope), the output where slope > 0 is known; dx may alias dy. */
 int blgnn_act_backward(const float *dy, int64_t lddy, const float *y, int64_t ldy, int32_t act,
                        const float *slope, int32_t M, int32_t N, float *dx, int64_t lddx,
                        void *stream);
+
+/* y = act(x), PReLU with one slope per column: the activation of a NodeEmbedding layer as its own step on the
+ * training path, where the backward needs the pre-activation (model/layers.py:55 `x = self.act(x)` with
+ * create_act('prelu', out_dim), model/layers_util.py:63-64); y may alias x. */
+int blgnn_act_forward(const float *x, int64_t ldx, int32_t act, const float *slope, int32_t M, int32_t N,
+                      float *y, int64_t ldy, void *stream);
 
 /* y[N, M] = x[M, N]^T. */
 int blgnn_transpose(const float *x, int64_t ldx, int32_t M, int32_t N, float *y, int64_t ldy,

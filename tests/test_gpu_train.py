@@ -135,6 +135,75 @@ def _oracle_loss(specs, sd, plain, of, labels):
     return torch.nn.functional.binary_cross_entropy(preds.view(-1), labels), acts
 
 
+@pytest.mark.parametrize("shared", [False, True])
+def test_prelu_forward_backward_trained_slopes(device, shared):
+    """nn.PReLU(out_dim) / nn.PReLU() as an autograd node (create_act: model/layers_util.py:63-64): y, dz and the
+    slope gradient against fp64 autograd; slopes of both signs and zero (the derivative tests the sign of the kept
+    pre-activation, not of the output); ragged shape"""
+    M, N = 2053, 70
+    g = torch.Generator().manual_seed(N + shared)
+    z, dy = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    a = torch.randn(1 if shared else N, generator=g) * 0.6
+    if not shared:
+        a[3] = 0.0
+    zr, ar = _leaf(z), _leaf(a)
+    ref = torch.nn.functional.prelu(zr, ar)
+    ref.backward(dy.double())
+    zd, ad = _leaf(z, device), _leaf(a, device)
+    got = ag.prelu(zd, ad)
+    got.backward(dy.to(device))
+    assert torch.equal(got.detach().cpu(), torch.nn.functional.prelu(z, a))
+    assert max_err(got, ref) < TOL
+    assert max_err(zd.grad, zr.grad) < TOL
+    assert ad.grad.shape == a.shape
+    assert max_err(ad.grad, ar.grad) < TOL
+
+
+@pytest.mark.parametrize("lower", ["gin", "gat", "gcn"])
+def test_llgnn_prelu_training_step_gradients(device, lower):
+    """A lower-level model whose NodeEmbedding layers carry act=prelu (reachable through --layer_k; model/layers.py:24-34
+    builds nn.PReLU(out_dim), in a GIN layer the same module inside the MLP and behind the conv): loss, activations and
+    every gradient INCLUDING the slopes' against fp64 autograd on the oracle"""
+    D = 64
+    ds = blgnn.make_synthetic(50, 300, seed=11, device=device)
+    flags = blgnn.make_flags("lower_level_gnn", lower_level_gnn_type=lower, D_lower=D, device=device)
+    for k in range(1, flags.layer_num + 1):
+        spec = getattr(flags, "layer_%d" % k)
+        if spec.startswith("NodeEmbedding") and "act=relu" in spec:
+            setattr(flags, "layer_%d" % k, spec.replace("act=relu", "act=prelu"))
+    model, data = build(flags, ds, seed=13)
+    gen = torch.Generator().manual_seed(3)
+    slopes = [m for m in model.modules() if isinstance(m, torch.nn.PReLU)]
+    assert len(slopes) == 4 and all(m.weight.numel() == D for m in slopes)
+    with torch.no_grad():
+        for m in slopes:
+            m.weight.copy_((torch.randn(D, generator=gen) * 0.4).to(device))          # both signs
+    specs = layer_specs(flags)
+    rng = np.random.default_rng(5)
+    pairs = ds.pair_gids[rng.choice(len(ds.pair_gids), size=40, replace=False)]
+    bd = blgnn.BatchData(pairs, ds, sampled_gids=np.unique(pairs), is_train=True, rng=np.random.default_rng(5))
+    ids = torch.as_tensor(np.vectorize(bd.merge_data['gids_to_batch_ind'].get)(bd.batch_gids))
+    of = oracle_flags(flags, ds)
+    sd = _oracle_state(model)
+    labels = bd.true_labels().cpu().double()
+    ref_loss, acts = _oracle_loss(specs, sd, plain_batch(bd, ds, torch.float64, with_pairs=ids), of, labels)
+    ref_loss.backward()
+    model.train()
+    loss = model(bd)
+    loss.backward()
+    assert max_err(loss, ref_loss) < TOL
+    for got, ref in zip(model.acts[1:-1], acts[1:]):
+        assert max_err(got, ref) < TOL
+    checked = 0
+    for name, p in model.named_parameters():
+        if name not in sd or not name.startswith("layers."):
+            continue
+        assert p.grad is not None, name
+        assert max_err(p.grad, sd[name].grad) < TOL, name
+        checked += name.endswith("act.weight")
+    assert checked == 4
+
+
 @pytest.mark.parametrize("D", [64, 128])
 def test_llgnn_training_step_gradients(device, D):
     """loss.backward() of the LL-GNN model (src/train.py:177-182): loss, every activation and every parameter
