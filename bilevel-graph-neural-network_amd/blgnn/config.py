@@ -160,6 +160,7 @@ def make_flags(model="higher_level_gnn", dataset="drugbank", lower_level_gnn_typ
     # segment-reduce launch (blgnn/layers.py ReadoutPlan; not a reference flag)
     f.fuse_readout = fuse_readout
     f.gmn_sp = gmn_sp                                  # pre-split GEMM operands in the GMN propagator (layers_gmn.py)
+    f.gmn_match_sp = True                              # d = 256: the attention on x's sp planes, sp result (gmn_match_sp.hip)
     f.gmn_match_streams = 1                            # side streams of the attention's size-class kernels (1 | 2)
     f.gmn_shared_prefix = True                         # pair batches: the layers in front of the first cross-graph
     #                                                    attention run on the distinct molecules (layers.py)

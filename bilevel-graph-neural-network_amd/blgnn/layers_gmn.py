@@ -20,6 +20,8 @@ What changes underneath (results equal to fp32 rounding):
     disappears and the edge kernel writes S straight into the f_node input.
 """
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -28,6 +30,9 @@ from .config import FLAGS
 from .layers_util import MLP, DerivedCache, act_name
 
 __all__ = ["GMNPropagator"]
+
+
+_MATCH_SP_ENV = os.environ.get("BLGNN_GMN_MATCH_SP", "1") != "0"      # A/B switch of the sp attention (bench / profiles)
 
 
 class GMNPropagator(nn.Module):
@@ -241,13 +246,25 @@ class GMNPropagator(nn.Module):
             max_nodes = self._max_nodes(batch_data)
             order = self._pair_order(batch_data, x.device)
 
-            u = torch.empty((n, D), dtype=torch.float32, device=x.device)
+            # the attention on the sp planes of x with an sp result (csrc/gmn_match_sp.hip; d = 256): no fp32 u, no
+            # split pass; in the shared-prefix case it reads the distinct molecules' planes through the row map
+            match_sp = D == ops.SpRows.BLOCK and getattr(FLAGS, "gmn_match_sp", True) and _MATCH_SP_ENV
+            x_planes = (f_sp_u if sh is not None else f_sp).cols(0, D)
+            x_rows = shared.row_map if sh is not None else None
+            u = None if match_sp else torch.empty((n, D), dtype=torch.float32, device=x.device)
+
+            def match_all():
+                if match_sp:
+                    ops.gmn_match_sp(seg, x_planes, u_sp, order, row_map=x_rows, x=x, max_nodes=max_nodes)
+                else:
+                    ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, order=order)
+                    ops.split_rows_sp(u, out=u_sp)
 
             def fork_match():
                 # FLAGS.gmn_match_streams = 2 puts the two rarer size classes of the attention on a second side stream
-                # (the three kernels are independent and each leaves most of the chip idle)
+                # (the three kernels are independent and each leaves most of the chip idle; fp32 attention only)
                 cur = torch.cuda.current_stream(x.device)
-                two = getattr(FLAGS, "gmn_match_streams", 1) >= 2
+                two = getattr(FLAGS, "gmn_match_streams", 1) >= 2 and not match_sp
                 side.wait_stream(cur)
                 if two:
                     side2 = self._side_stream(x.device, 1)
@@ -256,11 +273,14 @@ class GMNPropagator(nn.Module):
                         ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, classes=6, order=order)
                         u.record_stream(side2)
                 with torch.cuda.stream(side):
-                    ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, classes=1 if two else 0, order=order)
                     if two:
+                        ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, classes=1, order=order)
                         side.wait_stream(side2)
-                    ops.split_rows_sp(u, out=u_sp)
-                    u.record_stream(side)
+                        ops.split_rows_sp(u, out=u_sp)
+                    else:
+                        match_all()
+                    if u is not None:
+                        u.record_stream(side)
 
             # Where the attention forks off (FLAGS.gmn_match_fork): "message" (default) = beside the message GEMM AND the
             # edge kernel, "edge" = beside the edge kernel only.  The attention's workgroups (66-133 KB of LDS) and the
@@ -289,8 +309,7 @@ class GMNPropagator(nn.Module):
             if side is not None:
                 torch.cuda.current_stream(x.device).wait_stream(side)
             else:
-                ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, order=order)
-                ops.split_rows_sp(u, out=u_sp)
+                match_all()
             act = act_name(self.f_node.activation)
             kind, last = self._readout_of(model)
             tail = kind if (last and sh is None and act in ("relu", "identity")) else None

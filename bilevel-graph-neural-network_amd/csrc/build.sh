@@ -8,7 +8,7 @@ mkdir -p "$out" "$here/obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function"
 pids=()
-for f in runtime graph_layout gather readout linear linear_x6 linear_h3 gat_transform gmn_match gin_fused gin_x6 gin_h3 linear_sp gin_stack gin_stack_h3 link_head backward gat_backward gmn_backward gru; do
+for f in runtime graph_layout gather readout linear linear_x6 linear_h3 gat_transform gmn_match gmn_match_sp gin_fused gin_x6 gin_h3 linear_sp gin_stack gin_stack_h3 link_head backward gat_backward gmn_backward gru; do
   src="$here/$f.hip"; obj="$here/obj/$f.o"
   stale=0
   [[ -f "$obj" && "$src" -ot "$obj" ]] || stale=1

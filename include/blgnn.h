@@ -436,6 +436,26 @@ int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const float *x,
                     int32_t max_nodes, int32_t classes, const int32_t *pair_order,
                     const int32_t *class_counts_host, void *stream);
 
+/* The same attention for the pairs whose two graphs both have <= 64 nodes, on x in the sp format (the planes the
+ * producing layer wrote; d = 256: one scale block per row) with the result written straight into the sp format that
+ * f_node's first Linear reads (model/layers_gmn.py:45-50: in_f_node = cat([x, m, u])) -- no fp32 u, no separate split
+ * pass.  One wavefront per pair, both directions from the same staged rows, three fp16 MFMA products per fp32 product
+ * (csrc/gmn_match_sp.hip).  pair_order / class_counts_host as in blgnn_gmn_match (required): classes 0 and 1 are
+ * processed, the pairs of classes 2 and 3 are the caller's to run through blgnn_gmn_match(classes = 6) +
+ * blgnn_split_rows_sp_pairs.  row_map (optional, device int32 [merged atoms]): x plane row of every merged atom (the
+ * shared prefix of a pair batch keeps x on the distinct molecules: blgnn_expand_rows' map); x_rows = rows of the x
+ * planes.  The result row's scale is a bound (2 * max(own row's scale, largest partner scale)), not its maximum. */
+int blgnn_gmn_match_sp(const int32_t *seg, int32_t num_pairs, const void *xs, int64_t ldxs, const uint8_t *xe,
+                       int64_t ldxe, const int32_t *row_map, int64_t x_rows, void *us, int64_t ldus,
+                       uint8_t *ue, int64_t ldue, int32_t d, const int32_t *pair_order,
+                       const int32_t *class_counts_host, void *stream);
+
+/* blgnn_split_rows_sp for the rows of the listed pairs only (pair k = rows seg[2k] .. seg[2k + 2]): the pairs the
+ * fp32 attention kernels took when the others went through blgnn_gmn_match_sp. */
+int blgnn_split_rows_sp_pairs(const float *x, int64_t ldx, const int32_t *seg, const int32_t *pair_list,
+                              int32_t n_list, int32_t K, void *xs, int64_t ldxs, uint8_t *xe, int64_t ldxe,
+                              void *stream);
+
 /* GMNPropagator(f_node='GRU'): the gate arithmetic of torch.nn.GRUCell (model/layers_gmn.py:27-30,48-50) on the two
  * gate tables gi = in W_ih^T + b_ih, gh = h W_hh^T + b_hh ([n, 3D], gate order r | z | n; two blgnn_linear calls):
  *   out = (1 - z) * tanh(gi_n + r * gh_n) + z * h,  r = sigmoid(gi_r + gh_r),  z = sigmoid(gi_z + gh_z). */

@@ -3,6 +3,7 @@ blgnn_split_rows_sp / blgnn_join_rows_sp, the sp epilogues of blgnn_edge_relu_su
 every piece against the fp64 oracle at the 1e-5 bar, then the whole GMN models at d=256 / d=512 with the
 pipeline forced on (reference: model/layers_gmn.py:34-84, model/layers_util.py:44-57)."""
 
+import numpy as np
 import pytest
 import torch
 
@@ -394,3 +395,53 @@ def test_gmn_sp_pipeline_without_side_stream(device):
     finally:
         blgnn.make_flags = orig
     assert preds.shape[0] == 200
+
+
+@pytest.mark.parametrize("sizes,mapped", [
+    ([32, 32, 33, 31, 64, 64, 1, 64, 64, 1, 5, 7, 24, 24], False),     # tile edges of both kernels, one-node graphs
+    ([40, 38, 2, 60, 17, 9, 28, 0, 0, 13, 8, 8], False),               # an empty graph on either side
+    ([29, 31] * 40 + [50, 47] * 30 + [64, 3], True),                   # x kept on distinct rows behind a row map
+    ([12, 30, 64, 64, 65, 20, 128, 3, 129, 40, 7, 200, 33, 33], False),  # pairs above 64 nodes: fp32 kernels + their split
+])
+def test_gmn_match_sp(device, sizes, mapped):
+    """the attention on the sp planes of x with an sp result (model/layers_gmn.py:55-84) against the fp64 oracle on the
+    values the planes hold; rows of very different magnitude inside a pair (the partner scales ride on exp(cos), the
+    result row's scale is a bound); every row's pieces must be finite and its scale byte written"""
+    d = 256
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(off[-1])
+    ind = [(int(off[i]), int(off[i + 1])) for i in range(len(sizes))]
+    g = torch.Generator().manual_seed(len(sizes))
+    x = torch.randn(n, d, generator=g)
+    x[::3] *= 37.0
+    x[1::7] *= 1e-3
+    if n > 20:
+        x[11] = 0.0
+    seg = torch.as_tensor(off, dtype=torch.int32, device=device)
+    order = ops.match_pair_order(ind, device)
+    if mapped:                                                         # the planes hold a permutation of the rows (+ unused ones)
+        perm = torch.randperm(n + 50, generator=g)[:n]
+        xt = torch.zeros(n + 50, d)
+        xt[perm] = x
+        x_sp = ops.split_rows_sp(xt.to(device))
+        row_map = perm.to(torch.int32).to(device)
+    else:
+        x_sp, row_map = ops.split_rows_sp(x.to(device)), None
+    xh = ops.join_rows_sp(x_sp).cpu()                                  # what the planes hold (22 bits of x)
+    xin = xh[perm] if mapped else xh
+    ref = oracle.gmn_match(xin.double(), ind)
+    out = ops.SpRows(n, 4 * d, device)
+    out.planes.fill_(float("nan"))
+    out.scales.fill_(255)
+    u_sp = out.cols(3 * d, 4 * d)
+    ops.gmn_match_sp(seg, x_sp, u_sp, order, row_map=row_map, x=xin.to(device))
+    assert bool(torch.isfinite(u_sp.planes.float()).all()) and int(u_sp.scales.max()) < 255
+    assert bool(torch.isnan(out.planes[:, :6 * d].float()).all())      # nothing outside its column slice
+    got = ops.join_rows_sp(u_sp)
+    assert max_err(got, ref) < TOL
+    # per pair, relative to the pair's largest input magnitude (the unit the result's scale is bounded by)
+    for k in range(len(sizes) // 2):
+        a, b = ind[2 * k][0], ind[2 * k + 1][1]
+        if b > a:
+            scale = float(xin[a:b].abs().max())
+            assert float((got[a:b].cpu().double() - ref[a:b]).abs().max()) <= 2e-6 * max(scale, 1e-30), k
