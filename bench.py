@@ -124,7 +124,7 @@ def parse():
                     help="--train: run the iteration launch by launch instead of replaying its HIP graph")
     ap.add_argument("--no-gmn-sp", action="store_true",
                     help="GMN configs: the in-kernel operand split of blgnn_linear_h3 instead of the pre-split pipeline")
-    ap.add_argument("--gmn-match-fork", choices=("message", "edge"), default=None,
+    ap.add_argument("--gmn-match-fork", choices=("message", "edge", "split"), default=None,
                     help="GMN configs: the attention's side stream forks beside the message GEMM or beside the edge kernel")
     ap.add_argument("--gmn-match-streams", type=int, default=1, choices=(1, 2),
                     help="GMN configs: side streams of the cross-graph attention's size-class kernels")

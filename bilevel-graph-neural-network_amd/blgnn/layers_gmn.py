@@ -260,22 +260,34 @@ class GMNPropagator(nn.Module):
                     ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, order=order)
                     ops.split_rows_sp(u, out=u_sp)
 
-            def fork_match():
-                # FLAGS.gmn_match_streams = 2 puts the two rarer size classes of the attention on a second side stream
-                # (the three kernels are independent and each leaves most of the chip idle; fp32 attention only)
+            n_big = int(order[1][2]) + int(order[1][3])
+
+            def fork_match(which="all"):
+                # two side streams: the rarer size classes of the attention (pairs with a graph above 64 nodes: the fp32
+                # kernels + the split of their rows -- few workgroups, long latency) run beside the common ones instead
+                # of behind them.  FLAGS.gmn_match_streams = 2: both forked at the same point; fork "split" (below): the
+                # rare classes beside the message GEMM, the common ones beside the edge kernel.
                 cur = torch.cuda.current_stream(x.device)
-                two = getattr(FLAGS, "gmn_match_streams", 1) >= 2 and not match_sp
-                side.wait_stream(cur)
-                if two:
+                two = (getattr(FLAGS, "gmn_match_streams", 1) >= 2 or which != "all") and n_big > 0
+                if which in ("all", "big") and two:
                     side2 = self._side_stream(x.device, 1)
                     side2.wait_stream(cur)
                     with torch.cuda.stream(side2):
-                        ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, classes=6, order=order)
-                        u.record_stream(side2)
+                        if match_sp:
+                            ops.gmn_match_sp(seg, x_planes, u_sp, order, row_map=x_rows, x=x, max_nodes=max_nodes, part="big")
+                        else:
+                            ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, classes=6, order=order)
+                            u.record_stream(side2)
+                if which == "big":
+                    return
+                side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    if two:
+                    if two and match_sp:
+                        ops.gmn_match_sp(seg, x_planes, u_sp, order, row_map=x_rows, x=x, max_nodes=max_nodes, part="small")
+                        side.wait_stream(self._side_stream(x.device, 1))
+                    elif two:
                         ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, classes=1, order=order)
-                        side.wait_stream(side2)
+                        side.wait_stream(self._side_stream(x.device, 1))
                         ops.split_rows_sp(u, out=u_sp)
                     else:
                         match_all()
@@ -293,11 +305,15 @@ class GMNPropagator(nn.Module):
             fork = getattr(FLAGS, "gmn_match_fork", "message") if side is not None else None
             if fork == "message":
                 fork_match()
+            elif fork == "split":
+                fork_match("big")
             if sh is not None:
                 csr_u = shared.graph.csr()
                 pq, _ = ops.linear_sp(f_sp_u.cols(0, D), wpq, bpq)                        # [nu, 4D] = [P | Q], fp32
                 if fork == "edge":
                     fork_match()
+                elif fork == "split":
+                    fork_match("small")
                 ops.edge_relu_sum(csr_u, pq[:, :2 * D], pq[:, 2 * D:], out_sp=f_sp_u.cols(D, 3 * D))
                 w1a, w1b, b1, rw = self._node_weights_split()
                 part, _ = ops.linear_sp(f_sp_u.cols(0, 3 * D), w1a, b1, rowvec=ops.row_degree(csr_u), rowvec_w=rw)
@@ -305,6 +321,8 @@ class GMNPropagator(nn.Module):
                 pq, _ = ops.linear_sp(f_sp.cols(0, D), wpq, bpq)                          # [n, 4D] = [P | Q], fp32
                 if fork == "edge":
                     fork_match()
+                elif fork == "split":
+                    fork_match("small")
                 ops.edge_relu_sum(csr, pq[:, :2 * D], pq[:, 2 * D:], out_sp=f_sp.cols(D, 3 * D))
             if side is not None:
                 torch.cuda.current_stream(x.device).wait_stream(side)

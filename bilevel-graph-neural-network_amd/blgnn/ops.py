@@ -745,11 +745,12 @@ def gmn_match(seg, x, out=None, row_amax=None, max_nodes=0, classes=0, order=Non
     return u
 
 
-def gmn_match_sp(seg, x_sp, out_sp, order, row_map=None, x=None, max_nodes=0):
+def gmn_match_sp(seg, x_sp, out_sp, order, row_map=None, x=None, max_nodes=0, part="all"):
     """The attention on sp planes with an sp result (``SpRows`` [n, 256] both): pairs of two graphs <= 64 nodes by
     ``blgnn_gmn_match_sp``; any larger pairs of the batch through the fp32 kernels on ``x`` (fp32 rows, required then)
     and a split of just their rows.  ``order`` = ``match_pair_order(...)``; ``row_map`` int32 [n]: plane row of ``x_sp``
-    per merged atom (x kept on the distinct molecules), None = identity."""
+    per merged atom (x kept on the distinct molecules), None = identity.  ``part``: "small" / "big" run only one of the
+    two groups (they are independent: a caller may put them on different streams).  -> number of larger pairs."""
     n, d = out_sp.shape
     G = seg.numel() - 1
     if G % 2:
@@ -758,11 +759,12 @@ def gmn_match_sp(seg, x_sp, out_sp, order, row_map=None, x=None, max_nodes=0):
     if x_sp.shape[1] != d or (row_map is None and xr != n):
         raise ValueError("blgnn: gmn_match_sp operands differ in shape")
     counts = order[1]
-    call("blgnn_gmn_match_sp", _vec(seg, "seg", torch.int32, False), G // 2, *_sp_args(x_sp, xr, d),
-         _vec(row_map, "row_map", torch.int32), xr, *_sp_args(out_sp, n, d), d,
-         _vec(order[0], "order", torch.int32, False), counts.ctypes.data, _stream())
     n_big = int(counts[2]) + int(counts[3])
-    if n_big:
+    if part in ("all", "small"):
+        call("blgnn_gmn_match_sp", _vec(seg, "seg", torch.int32, False), G // 2, *_sp_args(x_sp, xr, d),
+             _vec(row_map, "row_map", torch.int32), xr, *_sp_args(out_sp, n, d), d,
+             _vec(order[0], "order", torch.int32, False), counts.ctypes.data, _stream())
+    if n_big and part in ("all", "big"):
         if x is None:
             raise ValueError("blgnn: this batch has pairs above 64 nodes: gmn_match_sp needs the fp32 rows of x for them")
         u = gmn_match(seg, x, max_nodes=max_nodes, classes=6, order=order)
@@ -770,7 +772,7 @@ def gmn_match_sp(seg, x_sp, out_sp, order, row_map=None, x=None, max_nodes=0):
         xp, ldx = _mat(u, "u")
         call("blgnn_split_rows_sp_pairs", xp, ldx, _vec(seg, "seg", torch.int32, False), big.data_ptr(), n_big, d,
              *_sp_args(out_sp, n, d), _stream())
-    return out_sp
+    return n_big
 
 
 def edge_relu_sum(csr, p, q, out=None, row_amax=None, out_sp=None):

@@ -32,6 +32,7 @@ typedef _Float16 f16x2s __attribute__((ext_vector_type(2)));
 typedef short s16x4s __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __attribute__((address_space(3))) s16x4s msp_lds_s16x4;
 typedef __attribute__((address_space(3))) void msp_lds_void;
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 
 struct MatchSpArgs {
     const int32_t *seg;
@@ -56,16 +57,14 @@ __device__ unsigned long long g_msp_stamps[16];          // diag build (csrc/dia
 #define MSP_T(k) do { } while (0)
 #endif
 
-template <int T> struct MatchSp {
-    static constexpr int R = 32 * T;                       // rows per graph (padded)
+template <int R_> struct MatchSp {
+    static constexpr int R = R_;                           // rows per graph in the chunk image (32, 48 or 64)
     static constexpr int GRAPH = R * 128;                  // one graph's chunk image: R rows x (64 B high | 64 B low)
     static constexpr int STAGE = 2 * GRAPH;
-    static constexpr int RING = 2 * STAGE;
-    static constexpr int ZLD = 36;                         // floats per staged result row (16-byte aligned rows)
-    static constexpr int ZST = 32 * ZLD * 4;
-    static constexpr int ARR = R * 4;                      // one per-row float array of one graph
-    static constexpr int BYTES = RING + ZST + 8 * ARR;     // 39 424 (T = 2) / 22 016 (T = 1): multiples of 128
-    static constexpr int WAVES = T == 1 ? 2 : 4;           // per workgroup: 44 KB (three per CU) / 158 KB (one per CU)
+    static constexpr int NST = 3;                          // ring stages: two chunks in flight beside the one being read
+    static constexpr int RING = NST * STAGE;
+    static constexpr int BYTES = RING + 4 * 64 * 4;        // + inverse norms and scale factors of both graphs' rows:
+    //   R = 64: 50 176 B (three wavefronts per CU), 48: 37 888 B (four), 32: 25 600 B (six)
 };
 
 // power of two from a biased exponent field; fields below 1 flush to zero
@@ -83,90 +82,86 @@ __device__ __forceinline__ float msp_sq(const f16x8 a, const f16x8 b) {       //
     return s;
 }
 
-// chunk C_ of both graphs into the ring stage at ST_: piece i of graph g only when the graph has rows there
-// (wave-uniform).  The request offset goes through a named scalar: with an element of an array whose size depends on
-// the template parameter as the builtin's argument, hipcc's host pass drops the kernel's stub without a diagnostic.
+// what lane l ^ 32 holds (v_permlane32_swap: no LDS round trip)
+__device__ __forceinline__ float msp_other_half(float v, int h) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);       // r[0] = low half's v, r[1] = high half's v
+    return __uint_as_float(h ? r[0] : r[1]);
+}
+
+// Chunk C_ of both graphs into the ring stage at ST_: ALWAYS 2 * NP requests -- a lane whose row the graph does not
+// have carries an offset beyond the resource's num_records: the range check answers with zeros and fetches nothing, so
+// the image's unused rows are zero, the number of requests per chunk is a constant and s_waitcnt vmcnt can count
+// chunks.  (The request offset goes through a named scalar: with an element of an array whose size depends on a
+// template parameter as the builtin's argument, hipcc's host pass drops the kernel's stub without a diagnostic.)
 #define MSP_DMA(ST_, C_)                                                                                               \
     do {                                                                                                              \
         char *st_ = (ST_);                                                                                            \
         _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_)                                                              \
-            _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_)                                                         \
-                if (i_ < Pn[g_]) {                                                                                    \
-                    const int vo_ = voff[g_][i_];                                                                     \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(RX, (msp_lds_void *)(st_ + g_ * GRAPH + i_ * 1024), 16, vo_, \
-                                                             (C_) * 128, 0, 0);                                       \
-                }                                                                                                     \
+            _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_) {                                                       \
+                const int vo_ = voff[g_][i_];                                                                         \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(RX, (msp_lds_void *)(st_ + g_ * GRAPH + i_ * 1024), 16, vo_,    \
+                                                         (C_) * 128, 0, 0);                                           \
+            }                                                                                                         \
     } while (0)
+#define MSP_WAIT_2() asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NP) : "memory")
+#define MSP_WAIT_1() asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory")
 
-template <int T, bool MAP>
-__global__ void __launch_bounds__(MatchSp<T>::WAVES * 64, 1) k_gmn_match_sp(const MatchSpArgs A) {
-    typedef MatchSp<T> W;
-    constexpr int R = W::R, GRAPH = W::GRAPH, STAGE = W::STAGE, ZLD = W::ZLD, NP = R / 8, NCH = 8;
-    extern __shared__ float4 msp_smem[];
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = blockIdx.x * W::WAVES + wid;
-    if (item >= A.n_list) return;                                              // (wave-uniform; no barrier in this kernel)
-    const int pair = A.list[item];
-    const int s0 = A.seg[2 * pair], s1 = A.seg[2 * pair + 1], s2 = A.seg[2 * pair + 2];
+// One pair with T1 / T2 tiles of 32 nodes in its two graphs (compile-time: the whole body is straight-line code, so
+// the scheduler can put one wavefront's vector work under its own MFMAs -- there is one wavefront per SIMD).
+template <int T1, int T2, int R, bool MAP>
+__device__ __forceinline__ void msp_pair(const MatchSpArgs &A, char *base, const int lane, const int s0, const int s1,
+                                         const int s2, const bool stamp_on) {
+    typedef MatchSp<R> W;
+    constexpr int GRAPH = W::GRAPH, STAGE = W::STAGE, NST = W::NST, NP = R / 8, NCH = 8, TM = T1 > T2 ? T1 : T2;
+    constexpr int TT[2] = {T1, T2};
     const int n[2] = {s1 - s0, s2 - s1};
-    if (n[0] > R || n[1] > R || (n[0] | n[1]) <= 0) return;                    // another size class / empty pair
     const int sg[2] = {s0, s1};
-    int Tn[2], Pn[2];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) { Tn[g] = (n[g] + 31) >> 5; Pn[g] = (n[g] + 7) >> 3; }
-
-#ifdef MSP_STAMP
-    const bool stamp_on = item == A.n_list / 2 + 1;
-#endif
-    MSP_T(0);
-    char *base = reinterpret_cast<char *>(msp_smem) + wid * W::BYTES;
-    float *zst = reinterpret_cast<float *>(base + W::RING);
-    float *arr = zst + 32 * ZLD;                                               // [8][R]: invn, pf, cA, cB x 2 graphs
-    auto invn = [&](int g) { return arr + (0 + g) * R; };
-    auto pfac = [&](int g) { return arr + (2 + g) * R; };
-    auto cfa = [&](int g) { return arr + (4 + g) * R; };
-    auto cfb = [&](int g) { return arr + (6 + g) * R; };
-
-    // the ring once to zero: rows no request of this pair writes are then finite (they meet E = 0 / masked lanes only)
-    {
-        const float4 z = f4_zero();
-#pragma unroll
-        for (int k = 0; k < W::RING / 1024; ++k) *reinterpret_cast<float4 *>(base + k * 1024 + lane * 16) = z;
-    }
+    float *arr = reinterpret_cast<float *>(base + W::RING);                    // [4][64]: inverse norms, scale factors x 2 graphs
+    auto invn = [&](int g) { return arr + (0 + g) * 64; };
+    auto pfac = [&](int g) { return arr + (2 + g) * 64; };
 
     const int r = lane & 31, h = lane >> 5;
     const int64_t rowb = A.ldxs * 2;                                           // bytes per plane row
     // ---- request plan: piece i of graph g = rows 8 i + (lane >> 3) of the chunk image, LDS slot lane & 7 <- global
     // 16-byte piece slot ^ ((row >> 1) & 7) (linear_sp.hip's swizzle: fragment reads of 16 rows and the transposed
     // reads of 4 rows x 64 B then touch every bank once)
+    const int64_t span = MAP ? A.x_rows * rowb : (int64_t)(n[0] + n[1]) * rowb;
+    const unsigned records = span > 0xfffff000ll ? 0xfffff000u : (unsigned)span;
     const __amdgpu_buffer_rsrc_t RX = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(A.xs) + (MAP ? (int64_t)0 : (int64_t)s0 * rowb)), 0,
-        (int)(unsigned)(MAP ? A.x_rows * rowb : (int64_t)(n[0] + n[1]) * rowb), 0x00020000);
+        const_cast<char *>(reinterpret_cast<const char *>(A.xs) + (MAP ? (int64_t)0 : (int64_t)s0 * rowb)), 0, (int)records,
+        0x00020000);
     int voff[2][NP];
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int row = 8 * i + (lane >> 3);
-            const int rc = row < n[g] ? row : (n[g] > 0 ? n[g] - 1 : 0);
-            int src = sg[g] - s0 + rc;
-            if (MAP) src = (i < Pn[g]) ? A.row_map[sg[g] + rc] : 0;
-            voff[g][i] = (int)((unsigned)src * (unsigned)rowb + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) << 4));
+            const bool ok = row < n[g];
+            int src = sg[g] - s0 + row;
+            if (MAP) src = ok ? A.row_map[sg[g] + row] : 0;
+            voff[g][i] = ok ? (int)((unsigned)src * (unsigned)rowb + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) << 4))
+                            : (int)0xfffff000u;                                // beyond num_records (+ the chunk offset: no wrap): zeros
         }
     // the rows' exponent bytes: lane r of either half holds row 32 t + r
-    int eb[2][T];
+    int eb[2][TM];
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
+        for (int t = 0; t < TT[g]; ++t) {
             const int row = 32 * t + r;
             const bool ok = row < n[g];
             const int64_t src = MAP ? (ok ? A.row_map[sg[g] + row] : 0) : (int64_t)(sg[g] + (ok ? row : 0));
             const int e = A.xe[src * A.ldxe];
             eb[g][t] = ok ? e : 0;
         }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");               // zero fill done before any request lands
+    // result rows by buffer stores: a row the graph does not have lies beyond its resource's num_records (no predicate)
+    __amdgpu_buffer_rsrc_t RU[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+        RU[g] = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(A.us + (int64_t)sg[g] * A.ldus), 0,
+                                                  (int)(n[g] > 0 ? ((int64_t)(n[g] - 1) * A.ldus + 512) * 2 : 0), 0x00020000);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -174,83 +169,103 @@ __global__ void __launch_bounds__(MatchSp<T>::WAVES * 64, 1) k_gmn_match_sp(cons
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int t = 0; t < T; ++t) asm volatile("" : "+v"(eb[g][t]));
+        for (int t = 0; t < TT[g]; ++t) asm volatile("" : "+v"(eb[g][t]));
+
+    // the 16 chunk loads of the kernel (pass 1: 0 .. 7, pass 2: 8 .. 15) form one sequence through the ring: load j
+    // goes to stage j % 3 and is issued two steps ahead; requests return in order, every load is 2 NP requests, so
+    // "at most 2 * 2 NP requests outstanding" means load j has landed (the result stores of pass 2 only add to the count)
 
     // ================================ pass 1: S, S^T and the squared norms ================================
     // C0[t2][t1]: rows = nodes of graph 2, columns (lanes) = nodes of graph 1;  C1[t1][t2]: the transpose
-    f32x16s C0[T][T], C1[T][T];
+    f32x16s C0[T2][T1], C1[T1][T2];
 #pragma unroll
-    for (int i = 0; i < T; ++i)
+    for (int i = 0; i < T2; ++i)
 #pragma unroll
-        for (int j = 0; j < T; ++j)
+        for (int j = 0; j < T1; ++j)
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { C0[i][j][k] = 0.f; C1[i][j][k] = 0.f; }
-    float nq[2][T];
+            for (int k = 0; k < 16; ++k) { C0[i][j][k] = 0.f; C1[j][i][k] = 0.f; }
+    float nq[2][TM];
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int t = 0; t < T; ++t) nq[g][t] = 0.f;
+        for (int t = 0; t < TM; ++t) nq[g][t] = 0.f;
     const int fsw = (r >> 1) & 7;                                              // (32 t + r) >> 1 & 7: the same for every tile
-    MSP_T(1);
     MSP_DMA(base, 0);
+    MSP_DMA(base + STAGE, 1);
+    MSP_T(1);
+    int stg = 0;                                                               // stage of the chunk being read
+#pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
+        {   // load c + 2 (pass 2's first two chunks behind pass 1's last two) into the stage read at step c - 1
+            const int nxt = stg == 0 ? 2 : stg - 1;
+            MSP_DMA(base + nxt * STAGE, (c + 2) & 7);
+        }
         if (c == 3) MSP_T(7);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MSP_WAIT_2();
         if (c == 3) MSP_T(8);
-        if (c + 1 < NCH) MSP_DMA(base + ((c + 1) & 1) * STAGE, c + 1);
-        const char *st = base + (c & 1) * STAGE;
+        const char *st = base + stg * STAGE;
+        stg = stg == NST - 1 ? 0 : stg + 1;
+        f16x8 a[2][2][TM][2];                                                  // [k step][graph][tile][piece]
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            f16x8 a[2][T][2];
             const int slot = (((2 * s + h) ^ fsw) << 4);
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
-                for (int t = 0; t < T; ++t)
-                    if (t < Tn[g]) {
-                        const int off = g * GRAPH + (32 * t + r) * 128 + slot;
-                        a[g][t][0] = *reinterpret_cast<const f16x8 *>(st + off);
-                        a[g][t][1] = *reinterpret_cast<const f16x8 *>(st + (off ^ 64));
-                        nq[g][t] += msp_sq(a[g][t][0], a[g][t][1]);
-                    }
-#pragma unroll
-            for (int t2 = 0; t2 < T; ++t2)
-#pragma unroll
-                for (int t1 = 0; t1 < T; ++t1)
-                    if (t2 < Tn[1] && t1 < Tn[0]) {
-                        C0[t2][t1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][t2][0], a[0][t1][0], C0[t2][t1], 0, 0, 0);
-                        C0[t2][t1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][t2][0], a[0][t1][1], C0[t2][t1], 0, 0, 0);
-                        C0[t2][t1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][t2][1], a[0][t1][0], C0[t2][t1], 0, 0, 0);
-                        C1[t1][t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][t1][0], a[1][t2][0], C1[t1][t2], 0, 0, 0);
-                        C1[t1][t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][t1][0], a[1][t2][1], C1[t1][t2], 0, 0, 0);
-                        C1[t1][t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][t1][1], a[1][t2][0], C1[t1][t2], 0, 0, 0);
-                    }
+                for (int t = 0; t < TT[g]; ++t) {
+                    const int off = g * GRAPH + (32 * t + r) * 128 + slot;
+                    a[s][g][t][0] = *reinterpret_cast<const f16x8 *>(st + off);
+                    a[s][g][t][1] = *reinterpret_cast<const f16x8 *>(st + (off ^ 64));
+                }
         }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int t2 = 0; t2 < T2; ++t2)
+#pragma unroll
+                for (int t1 = 0; t1 < T1; ++t1) {
+                    C0[t2][t1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][1][t2][0], a[s][0][t1][0], C0[t2][t1], 0, 0, 0);
+                    C1[t1][t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][0][t1][0], a[s][1][t2][0], C1[t1][t2], 0, 0, 0);
+                    C0[t2][t1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][1][t2][0], a[s][0][t1][1], C0[t2][t1], 0, 0, 0);
+                    C1[t1][t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][0][t1][0], a[s][1][t2][1], C1[t1][t2], 0, 0, 0);
+                    C0[t2][t1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][1][t2][1], a[s][0][t1][0], C0[t2][t1], 0, 0, 0);
+                    C1[t1][t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][0][t1][1], a[s][1][t2][0], C1[t1][t2], 0, 0, 0);
+                }
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int t = 0; t < TT[g]; ++t) nq[g][t] += msp_sq(a[s][g][t][0], a[s][g][t][1]);
+            // the norms' vector work under the matrix cores (one wavefront per SIMD: nobody else fills the gaps)
+#pragma unroll
+            for (int k = 0; k < 6 * T1 * T2; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (16 * (T1 + T2) + 6 * T1 * T2 - 1) / (6 * T1 * T2), 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
     MSP_T(2);
-    // pass 2's first chunk on its way while the softmax runs (both stages are free: every fragment read has returned)
-    MSP_DMA(base, 0);
 
     // ================================ softmax ================================
-    float invl[2][T];
+    float invl[2][TM];
     int eref[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         int em = 0;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const float nrm = nq[g][t] + __shfl_xor(nq[g][t], 32, WAVE);
+        for (int t = 0; t < TT[g]; ++t) {
+            const float nrm = nq[g][t] + msp_other_half(nq[g][t], h);
             invl[g][t] = 1.f / fmaxf(sqrtf(nrm), 1e-12f);
             invn(g)[32 * t + r] = invl[g][t];
             em = eb[g][t] > em ? eb[g][t] : em;
         }
         eref[g] = __builtin_amdgcn_readfirstlane(group_max(em, WAVE));
     }
-    int eout[2][T];
+    int eout[2][TM];
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
+        for (int t = 0; t < TT[g]; ++t) {
             const int row = 32 * t + r;
             pfac(g)[row] = row < n[g] ? msp_pow2(127 + 10 + eb[g][t] - eref[g]) : 0.f;
             const int eo = (eb[g][t] > eref[1 - g] ? eb[g][t] : eref[1 - g]) + 1;
@@ -258,140 +273,195 @@ __global__ void __launch_bounds__(MatchSp<T>::WAVES * 64, 1) k_gmn_match_sp(cons
             if (row < n[g] && h == 0) A.ue[(int64_t)(sg[g] + row) * A.ldue] = (uint8_t)eout[g][t];
         }
     asm volatile("" ::: "memory");
-    // E fragments: Ef[d][to][tp][s][piece], own graph d on the lanes
-    f16x8 Ef[2][T][T][2][2];
+    // E fragments Ef[d][to][tp][s][piece] (own graph d on the lanes) carry everything that multiplies the partner rows:
+    // exp(cos) x the partner row's scale 2^(e_p - e_max) x the own row's -2^(e_max - e_out) / sum, times 2^10 (a softmax
+    // weight is ~1 / n: without the factor its low piece would be an fp16 subnormal and the pair would hold 18 bits, not 22);
+    // Df[d][to][s]: the own row's 2^(e_own - e_out + 10) on the diagonal of a 32 x 32 block (one fp16 piece: a power of
+    // two), which adds the own values in the same product.  The product leaves the matrix cores as 2^10 x the result in
+    // the result row's unit.
+    f16x8 Ef[2][TM][TM][2][2], Df[2][TM][2];
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
         const int gp = 1 - d;
 #pragma unroll
-        for (int to = 0; to < T; ++to) {
+        for (int to = 0; to < TT[d]; ++to) {
             float sum = 0.f;
+            const float io = invl[d][to] * 1.44269504088896340736f;          // exp(x) = 2^(x log2 e)
 #pragma unroll
-            for (int tp = 0; tp < T; ++tp) {
-                if (to < Tn[d] && tp < Tn[gp]) {
-                    const f32x16s Cc = d == 0 ? C0[tp][to] : C1[tp][to];
-                    float ev[16];
+            for (int tp = 0; tp < TT[gp]; ++tp) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int p0 = 32 * tp + 8 * q + 4 * h;
-                        const float4 ip = *reinterpret_cast<const float4 *>(invn(gp) + p0);
-                        const float4 pf = *reinterpret_cast<const float4 *>(pfac(gp) + p0);
-                        const float ipv[4] = {ip.x, ip.y, ip.z, ip.w}, pfv[4] = {pf.x, pf.y, pf.z, pf.w};
+                for (int q = 0; q < 4; ++q) {
+                    const int p0 = 32 * tp + 8 * q + 4 * h;
+                    const float4 ip = *reinterpret_cast<const float4 *>(invn(gp) + p0);
+                    const float4 pf = *reinterpret_cast<const float4 *>(pfac(gp) + p0);
+                    const float ipv[4] = {ip.x, ip.y, ip.z, ip.w}, pfv[4] = {pf.x, pf.y, pf.z, pf.w};
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float e = (p0 + j < n[gp]) ? expf(Cc[4 * q + j] * invl[d][to] * ipv[j]) : 0.f;
-                            sum += e;
-                            ev[4 * q + j] = e * pfv[j];
-                        }
+                    for (int j = 0; j < 4; ++j) {
+                        const float cv = d == 0 ? C0[tp][to][4 * q + j] : C1[tp][to][4 * q + j];
+                        const float e = (p0 + j < n[gp]) ? __builtin_amdgcn_exp2f(cv * io * ipv[j]) : 0.f;
+                        sum += e;
+                        if (d == 0) C0[tp][to][4 * q + j] = e * pfv[j]; else C1[tp][to][4 * q + j] = e * pfv[j];
                     }
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const _Float16 e1 = (_Float16)ev[8 * s + j];
-                            Ef[d][to][tp][s][0][j] = e1;
-                            Ef[d][to][tp][s][1][j] = (_Float16)(ev[8 * s + j] - (float)e1);
-                        }
                 }
             }
-            if (to < Tn[d]) {
-                sum += __shfl_xor(sum, 32, WAVE);
-                const int row = 32 * to + r;
-                cfa(d)[row] = msp_pow2(127 + eb[d][to] - eout[d][to]);
-                cfb(d)[row] = sum > 0.f ? -msp_pow2(127 + eref[gp] - 10 - eout[d][to]) / sum : 0.f;
+            sum += msp_other_half(sum, h);
+            const float a_ = msp_pow2(127 + eb[d][to] - eout[d][to]);
+            const float b_ = sum > 0.f ? -msp_pow2(127 + eref[gp] - eout[d][to]) / sum : 0.f;   // (x 2^10 with the factor on the partner rows)
+#pragma unroll
+            for (int tp = 0; tp < TT[gp]; ++tp) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float ev = (d == 0 ? C0[tp][to][8 * s + j] : C1[tp][to][8 * s + j]) * b_;
+                        // ONE rounded product for both pieces: left to itself hipcc forms the high piece from the fp32
+                        // product and the low piece against fp16(fused product) -- at a tie the two differ by one fp16 step
+                        asm volatile("" : "+v"(ev));
+                        const _Float16 e1 = (_Float16)ev;
+                        Ef[d][to][tp][s][0][j] = e1;
+                        Ef[d][to][tp][s][1][j] = (_Float16)(ev - (float)e1);
+                    }
+                // the pieces are formed HERE: without the pin hipcc keeps the fp32 values and converts them again in
+                // every chunk of pass 2 (~400 instructions per chunk)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) asm volatile("" : "+v"(Ef[d][to][tp][s][pc]));
+            }
+            const _Float16 ah = (_Float16)(a_ * 1024.f);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    Df[d][to][s][j] = (16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) == r ? ah : (_Float16)0.f;
+                asm volatile("" : "+v"(Df[d][to][s]));
             }
         }
     }
     asm volatile("" ::: "memory");
 
-    // ================================ pass 2: U = X_own - diag(1 / sum) E^T X_partner ================================
-    // transposed-read plan (ds_read_b64_tr_b16): lane 4 q + p of a 16-lane group addresses row q, columns 4 p .. 4 p + 3 of
-    // the group's 16 columns; lanes 16 G .. 16 G + 15 of a half take columns 16 G ..; the half h takes partner rows
-    // 16 s + 4 h .. + 3 and 16 s + 8 + 4 h .. + 3 (the accumulator's row order)
-    MSP_T(3);
+    // ================================ pass 2: U^T = X_own^T D - X_partner^T E ================================
+    // A operands = the rows of both graphs transposed (rows of the product = the chunk's 32 features, k = node), fetched
+    // with ds_read_b64_tr_b16 in the accumulator's row order: lane 4 q + p of a 16-lane group addresses row q, columns
+    // 4 p .. 4 p + 3 of the group's 16 columns; lanes 16 G .. 16 G + 15 of a half take columns 16 G ..; the half h takes
+    // rows 16 s + 4 h .. + 3 and 16 s + 8 + 4 h .. + 3.  B operands = E and D as they stand.  Result tile: the own node on
+    // the lane, features (k & 3) + 8 (k >> 2) + 4 h in the registers, already in the result row's unit: each group of
+    // four registers is one 8-byte piece of the row's two planes.
     const int tq = (lane & 15) >> 2, tpp = lane & 3, tG = (lane >> 4) & 1;
     const int tsw = (2 * h + (tq >> 1)) & 7;                                   // (row >> 1) & 7 of the first block's row
     const int trow0 = (4 * h + tq) * 128 + (((2 * tG + (tpp >> 1)) ^ tsw) << 4) + 8 * (tpp & 1);
     const int trow1 = (4 * h + tq + 8) * 128 + (((2 * tG + (tpp >> 1)) ^ tsw ^ 4) << 4) + 8 * (tpp & 1);
-    const int cg = lane & 7, rw = lane >> 3;                                   // row-wise stage: 4 columns cg, row 8 w + rw
+    const int uoff = r * (int)(A.ldus * 2) + 8 * h;                            // this lane's row inside a 32-row tile, its 8 bytes
+    MSP_T(3);
+#pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
+        if (c + 2 < NCH) {
+            const int nxt = stg == 0 ? 2 : stg - 1;
+            MSP_DMA(base + nxt * STAGE, c + 2);
+        }
         if (c == 3) MSP_T(5);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (c + 2 < NCH) MSP_WAIT_2();
+        else if (c + 1 < NCH) MSP_WAIT_1();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (c == 3) MSP_T(6);
-        if (c + 1 < NCH) MSP_DMA(base + ((c + 1) & 1) * STAGE, c + 1);
-        const char *st = base + (c & 1) * STAGE;
+        const char *st = base + stg * STAGE;
+        stg = stg == NST - 1 ? 0 : stg + 1;
+        f16x8 Xt[2][TM][2][2];                                                 // [graph][tile][k step][piece]
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            const int gp = 1 - d;
-            f16x8 Bf[T][2][2];
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int tp = 0; tp < T; ++tp)
+            for (int t = 0; t < TT[g]; ++t)
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    if (tp < Tn[gp]) {
-                        const int o0 = gp * GRAPH + (32 * tp + 16 * s) * 128;
+                for (int s = 0; s < 2; ++s) {
+                    const int o0 = g * GRAPH + (32 * t + 16 * s) * 128;
 #pragma unroll
-                        for (int pc = 0; pc < 2; ++pc) {
-                            const s16x4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                (msp_lds_s16x4 *)(st + ((o0 + trow0) ^ (64 * pc))));
-                            const s16x4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                (msp_lds_s16x4 *)(st + ((o0 + trow1) ^ (64 * pc))));
-                            const f16x4 l4 = __builtin_bit_cast(f16x4, lo), h4 = __builtin_bit_cast(f16x4, hi);
-                            Bf[tp][s][pc] = f16x8{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
-                        }
-                    }
-#pragma unroll
-            for (int to = 0; to < T; ++to) {
-                if (to >= Tn[d]) continue;
-                f32x16s Z;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) Z[k] = 0.f;
-#pragma unroll
-                for (int tp = 0; tp < T; ++tp)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-                        if (tp < Tn[gp]) {
-                            Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ef[d][to][tp][s][0], Bf[tp][s][0], Z, 0, 0, 0);
-                            Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ef[d][to][tp][s][0], Bf[tp][s][1], Z, 0, 0, 0);
-                            Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ef[d][to][tp][s][1], Bf[tp][s][0], Z, 0, 0, 0);
-                        }
-                // result tile -> LDS: row (own node) = (k & 3) + 8 (k >> 2) + 4 h, column (feature) = r
-#pragma unroll
-                for (int k = 0; k < 16; ++k) zst[((k & 3) + 8 * (k >> 2) + 4 * h) * ZLD + r] = Z[k];
-                asm volatile("" ::: "memory");
-                // row-wise: u = x_own - z / sum in the result row's unit, two fp16 pieces, 16-byte stores
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const int lrow = 8 * w + rw, orow = 32 * to + lrow;
-                    const float4 z4 = *reinterpret_cast<const float4 *>(zst + lrow * ZLD + 4 * cg);
-                    const int xo = d * GRAPH + orow * 128 + (((cg >> 1) ^ ((orow >> 1) & 7)) << 4) + 8 * (cg & 1);
-                    const f16x4 x1 = *reinterpret_cast<const f16x4 *>(st + xo);
-                    const f16x4 x2 = *reinterpret_cast<const f16x4 *>(st + (xo ^ 64));
-                    const float ca = cfa(d)[orow], cb = cfb(d)[orow];
-                    f32x4v v;
-                    v[0] = fmaf(z4.x, cb, ((float)x1[0] + (float)x2[0]) * ca);
-                    v[1] = fmaf(z4.y, cb, ((float)x1[1] + (float)x2[1]) * ca);
-                    v[2] = fmaf(z4.z, cb, ((float)x1[2] + (float)x2[2]) * ca);
-                    v[3] = fmaf(z4.w, cb, ((float)x1[3] + (float)x2[3]) * ca);
-                    const f16x4 h1 = __builtin_convertvector(v, f16x4);
-                    const f16x4 h2 = __builtin_convertvector(v - __builtin_convertvector(h1, f32x4v), f16x4);
-                    const uint2 u1 = __builtin_bit_cast(uint2, h1), u2 = __builtin_bit_cast(uint2, h2);
-                    const bool odd = lane & 1;
-                    const uint2 keep = odd ? u2 : u1, send = odd ? u1 : u2;
-                    uint2 recv;
-                    recv.x = (unsigned)__shfl_xor((int)send.x, 1, WAVE);
-                    recv.y = (unsigned)__shfl_xor((int)send.y, 1, WAVE);
-                    const uint4 out = odd ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y);
-                    if (orow < n[d]) {
-                        _Float16 *dst = A.us + (int64_t)(sg[d] + orow) * A.ldus + c * 64 + 4 * (cg & ~1) + (odd ? 32 : 0);
-                        *reinterpret_cast<uint4 *>(dst) = out;
+                    for (int pc = 0; pc < 2; ++pc) {
+                        const s16x4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (msp_lds_s16x4 *)(st + ((o0 + trow0) ^ (64 * pc))));
+                        const s16x4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (msp_lds_s16x4 *)(st + ((o0 + trow1) ^ (64 * pc))));
+                        const f16x4 l4 = __builtin_bit_cast(f16x4, lo), h4 = __builtin_bit_cast(f16x4, hi);
+                        Xt[g][t][s][pc] = f16x8{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
                     }
                 }
-                asm volatile("" ::: "memory");
+        // the tiles (d, to) of this chunk as a pipeline: the product of tile i + 1 is issued in front of the piece split
+        // and the stores of tile i, and the scheduler is told to alternate them
+        f32x16s Z[2];
+        auto product = [&](int i) {
+            const int d = i < T1 ? 0 : 1, to = i < T1 ? i : i - T1, gp = 1 - d;
+            f32x16s z;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) z[k] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                z = __builtin_amdgcn_mfma_f32_32x32x16_f16(Xt[d][to][s][0], Df[d][to][s], z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_f32_32x32x16_f16(Xt[d][to][s][1], Df[d][to][s], z, 0, 0, 0);
+            }
+#pragma unroll
+            for (int tp = 0; tp < TT[gp]; ++tp)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(Xt[gp][tp][s][0], Ef[d][to][tp][s][0], z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(Xt[gp][tp][s][1], Ef[d][to][tp][s][0], z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(Xt[gp][tp][s][0], Ef[d][to][tp][s][1], z, 0, 0, 0);
+                }
+            return z;
+        };
+        Z[0] = product(0);
+#pragma unroll
+        for (int i = 0; i < T1 + T2; ++i) {
+            const int d = i < T1 ? 0 : 1, to = i < T1 ? i : i - T1;
+            if (i + 1 < T1 + T2) Z[(i + 1) & 1] = product(i + 1);
+            const f32x16s z = Z[i & 1];
+            const int ub = uoff + to * 32 * (int)(A.ldus * 2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4v v, rs;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = z[4 * q + j] * 0.0009765625f;                // 2^-10
+                const f16x4 h1 = __builtin_convertvector(v, f16x4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rs[j] = fmaf((float)h1[j], -1.f, v[j]);
+                const f16x4 h2 = __builtin_convertvector(rs, f16x4);
+                // features 8 q + 4 h .. + 3 of chunk c: 8 bytes of the high plane, 8 of the low plane 64 bytes on
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2v, h1), RU[d], ub + 16 * q, c * 128, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2v, h2), RU[d], ub + 16 * q + 64, c * 128, 0);
+            }
+            if (i + 1 < T1 + T2) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+                }
             }
         }
     }
     MSP_T(4);
+}
+
+template <int R, bool MAP>
+__global__ void __launch_bounds__(64, 1) k_gmn_match_sp(const MatchSpArgs A) {
+    extern __shared__ float4 msp_smem[];
+    const int lane = threadIdx.x;
+    const int item = blockIdx.x;
+    const int pair = A.list[item];
+    const int s0 = A.seg[2 * pair], s1 = A.seg[2 * pair + 1], s2 = A.seg[2 * pair + 2];
+    const int n0 = s1 - s0, n1 = s2 - s1;
+    if (n0 > R || n1 > R || (n0 | n1) <= 0) return;                            // another size class / empty pair
+#ifdef MSP_STAMP
+    const bool stamp_on = item == (int)gridDim.x / 2 + 1;
+#else
+    const bool stamp_on = false;
+#endif
+    MSP_T(0);
+    char *base = reinterpret_cast<char *>(msp_smem);
+    // (an empty graph runs as one tile of rows that are all beyond the resource: zeros, masked in the softmax)
+    if (R <= 32) msp_pair<1, 1, R, MAP>(A, base, lane, s0, s1, s2, stamp_on);
+    else if (n0 > 32 && n1 > 32) msp_pair<2, 2, R, MAP>(A, base, lane, s0, s1, s2, stamp_on);
+    else if (n0 > 32) msp_pair<2, 1, R, MAP>(A, base, lane, s0, s1, s2, stamp_on);
+    else if (n1 > 32) msp_pair<1, 2, R, MAP>(A, base, lane, s0, s1, s2, stamp_on);
+    else msp_pair<1, 1, R, MAP>(A, base, lane, s0, s1, s2, stamp_on);
 }
 
 // fp32 rows -> sp format for the rows of the listed pairs only (the pairs the fp32 attention kernels took)
@@ -415,18 +485,17 @@ __global__ void __launch_bounds__(256) k_split_sp_pairs(const float *__restrict_
     }
 }
 
-template <int T, bool MAP>
+template <int R, bool MAP>
 static int launch_match_sp(const MatchSpArgs &A, hipStream_t s) {
-    typedef MatchSp<T> W;
+    typedef MatchSp<R> W;
     static bool declared = false;
-    const int bytes = W::WAVES * W::BYTES;
     if (!declared) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gmn_match_sp<T, MAP>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gmn_match_sp<R, MAP>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, W::BYTES) != hipSuccess)
             return fail(BLGNN_ERR_LAUNCH, "gmn_match_sp: cannot raise the dynamic LDS limit");
         declared = true;
     }
-    hipLaunchKernelGGL((k_gmn_match_sp<T, MAP>), dim3((A.n_list + W::WAVES - 1) / W::WAVES), dim3(W::WAVES * 64), bytes, s, A);
+    hipLaunchKernelGGL((k_gmn_match_sp<R, MAP>), dim3(A.n_list), dim3(64), W::BYTES, s, A);
     return launch_status("gmn_match_sp");
 }
 
@@ -448,7 +517,7 @@ extern "C" int blgnn_gmn_match_sp(const int32_t *seg, int32_t num_pairs, const v
     BLGNN_CHECK_ARG(class_counts_host[0] >= 0 && class_counts_host[1] >= 0 &&
                     (int64_t)class_counts_host[0] + class_counts_host[1] <= num_pairs, "gmn_match_sp: bad class counts");
     BLGNN_CHECK_ARG(x_rows > 0, "gmn_match_sp: x_rows");
-    if (row_map && x_rows * ldxs * 2 >= ((int64_t)1 << 32))
+    if (row_map && x_rows * ldxs * 2 > 0xfffff000ll)
         return fail(BLGNN_ERR_UNSUPPORTED, "gmn_match_sp: mapped x planes must stay below 4 GiB (32-bit buffer offsets)");
     if (ldxs * 2 * 128 >= ((int64_t)1 << 31)) return fail(BLGNN_ERR_UNSUPPORTED, "gmn_match_sp: plane rows too long");
     MatchSpArgs A;
@@ -459,12 +528,12 @@ extern "C" int blgnn_gmn_match_sp(const int32_t *seg, int32_t num_pairs, const v
     int rc = BLGNN_OK;
     if (class_counts_host[0] > 0) {
         A.list = pair_order; A.n_list = class_counts_host[0];
-        rc = row_map ? launch_match_sp<1, true>(A, s) : launch_match_sp<1, false>(A, s);
+        rc = row_map ? launch_match_sp<32, true>(A, s) : launch_match_sp<32, false>(A, s);
         if (rc != BLGNN_OK) return rc;
     }
     if (class_counts_host[1] > 0) {
         A.list = pair_order + class_counts_host[0]; A.n_list = class_counts_host[1];
-        rc = row_map ? launch_match_sp<2, true>(A, s) : launch_match_sp<2, false>(A, s);
+        rc = row_map ? launch_match_sp<64, true>(A, s) : launch_match_sp<64, false>(A, s);
     }
     return rc;
 }
