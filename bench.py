@@ -80,7 +80,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS),
                     help="index into BASELINE.json configs (default 2: DrugCombo d=256 B=8192 GMN)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
@@ -103,7 +103,8 @@ def parse():
     ap.add_argument("--train", action="store_true",
                     help="instead of the forward metric: time TRAINING steps of the bi-level model at the DrugBank shape "
                          "(molecular sweep with gradients -> interaction level -> BCE -> backward -> SGD; "
-                         "src/train.py:75-108,177-182) and print one JSON line for them")
+                         "src/train.py:75-108,177-182) and print one JSON line for them; with --config 5 the DrugCombo "
+                         "bi-level model, with --config 2 / 4 the pair-batched GMN model (eager)")
     ap.add_argument("--readout-with-upper", action="store_true")
     ap.add_argument("--gmn-fused-amax", action="store_true",
                     help="GMN configs: the producers of the f_node input merge its row magnitudes (atomic maximum) instead "
@@ -1071,8 +1072,72 @@ def run_train(args, D, transform, steps, warmup):
     return out
 
 
+def run_train_gmn(args, D, transform, steps, warmup):
+    """Training step of the pair-batched GMN model (lower_level_gmn: GIN + GMNPropagator x3, src/config.py:329-350) at the
+    BASELINE configs[2] / [4] shape, one GPU: per iteration a fresh pair batch (batch / 2 positives + as many sampled
+    negatives, every molecule appended once per pair: src/batch.py:105-144), forward with train-mode BatchNorm, BCE,
+    backward, SGD step -- what src/train.py:177-182 does.  Eager: the merged graph changes shape with every batch, so
+    the iteration is not captured; every forward and backward step is a libblgnn kernel behind autograd nodes."""
+    import numpy as np
+    import torch
+    import blgnn
+    from blgnn.batch import BatchData
+    cfg = CONFIGS[args.config]
+    device = D.device
+    d, pos_per_step = cfg["d"], cfg["batch"] // 2
+    ds = blgnn.make_synthetic(cfg["drugs"], cfg["pairs"], shape=cfg["shape"], seed=SEED + 7, device=device)
+    flags = blgnn.make_flags("lower_level_gmn", lower_level_gnn_type="gin", D_lower=d, device=device,
+                             batch_size=cfg["batch"], feature_transform=transform)
+    blgnn.set_flags(flags)
+    torch.manual_seed(SEED)
+    data = blgnn.TrainData(ds, device=device)
+    model = blgnn.Model(data).to(device)
+    model.train()
+    params = [p for k, p in model.named_parameters() if k.startswith("layers.")]
+    opt = torch.optim.SGD(params, lr=0.01, momentum=0.9)
+    rng = np.random.default_rng(SEED)
+    losses, atoms = [], []
+
+    def step(_i):
+        pos = ds.pair_gids[rng.choice(len(ds.pair_gids), size=pos_per_step, replace=False)]
+        bd = BatchData(pos, ds, sampled_gids=np.unique(pos), is_train=True, unique_graphs=False, rng=rng)
+        opt.zero_grad(set_to_none=True)
+        loss = model(bd)
+        loss.backward()
+        opt.step()
+        losses.append(loss.detach().clone())
+        atoms.append(int(bd.merge_data['merge'].x.shape[0]))
+        return len(bd.batch_gids)
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    scored = 0
+    for i in range(steps):
+        scored += step(i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    first, last = float(torch.stack(losses[:3]).mean()), float(torch.stack(losses[-3:]).mean())
+    if not (first == first and last == last):
+        raise SystemExit("bench.py --train: the loss is not finite")
+    return {"metric": "DDI edge-pairs/sec (GMN TRAINING step: forward + backward + SGD)", "value": scored / el,
+            "unit": "pairs/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * el / steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "TRAINING, %s-shape lower-level GMN (GIN + GMNPropagator x3, pair batches), d=%d: %d positive "
+                                   "and as many sampled negative pairs per step, a fresh batch (merge, CSR, segments) built on the "
+                                   "host inside every timed step" % (cfg["shape"], d, pos_per_step),
+                       "baseline_config_index": args.config, "atoms_per_step_mean": float(np.mean(atoms[-steps:])),
+                       "optimizer": "SGD(momentum 0.9)", "iteration": "eager (the batch graph changes shape every step)",
+                       "arithmetic": "exact-f32 MFMA products in both directions (blgnn/autograd.py)",
+                       "loss_first3_mean": first, "loss_last3_mean": last}}
+
+
 def main():
     args = parse()
+    # --train without --config keeps timing the bi-level model (configs[1] shape); --train --config 2 / 4: the GMN model
+    gmn_train = args.train and args.config is not None and CONFIGS[args.config]["kind"] == "gmn"
+    if args.config is None:
+        args.config = 2
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)
     if os.environ.get("BLGNN_BENCH_RENDEZVOUS_ONLY"):
@@ -1083,7 +1148,7 @@ def main():
     if args.train:
         if D.world != 1:
             raise SystemExit("bench.py --train measures one GPU")
-        print(json.dumps(run_train(args, D, transform, args.steps, args.warmup)), flush=True)
+        print(json.dumps((run_train_gmn if gmn_train else run_train)(args, D, transform, args.steps, args.warmup)), flush=True)
         D.close()
         return 0
     cfg = CONFIGS[args.config]

@@ -70,6 +70,7 @@ SIGNATURES = {
                         _p, _p, _p, _i64, _p, _i32, _p, _p, _p, _i64, _i32, _p],
     "blgnn_hadamard": [_p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p],
     "blgnn_gru_gates": [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p],
+    "blgnn_gru_gates_backward": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p],
     "blgnn_gmn_match": [_p, _i32, _p, _i64, _p, _i64, _i32, _p, _i32, _i32, _p, _p, _p],
     "blgnn_gmn_match_sp": [_p, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _p, _p, _p],
     "blgnn_split_rows_sp_pairs": [_p, _i64, _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p],

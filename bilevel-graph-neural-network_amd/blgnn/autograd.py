@@ -25,7 +25,7 @@ import torch
 
 from . import ops
 
-__all__ = ["linear", "prelu", "gat_conv", "gcn_conv", "multi_edge_gat", "edge_relu_sum", "gmn_match", "spmm_sum", "batch_norm_train", "segment_reduce_multi", "l2_normalize", "pair_gather",
+__all__ = ["linear", "prelu", "gru_gates", "gat_conv", "gcn_conv", "multi_edge_gat", "edge_relu_sum", "gmn_match", "spmm_sum", "batch_norm_train", "segment_reduce_multi", "l2_normalize", "pair_gather",
            "training_active", "set_batch_norm_sync"]
 
 
@@ -69,6 +69,27 @@ class _PRelu(torch.autograd.Function):
 
 def prelu(z, slope):
     return _PRelu.apply(z, slope)
+
+
+class _GruGates(torch.autograd.Function):
+    """h' = GRUCell's gate arithmetic on gi = in W_ih^T + b_ih, gh = h W_hh^T + b_hh and the state h (torch.nn.GRUCell;
+    GMNPropagator(f_node='GRU'): model/layers_gmn.py:27-30,48-50).  The two products are ``linear`` nodes around it."""
+
+    @staticmethod
+    def forward(ctx, gi, gh, h):
+        gi, gh, h = gi.detach(), gh.detach(), h.detach()
+        ctx.save_for_backward(gi, gh, h)
+        return ops.gru_gates(gi, gh, h)
+
+    @staticmethod
+    def backward(ctx, g):
+        gi, gh, h = ctx.saved_tensors
+        dgi, dgh, dh = ops.gru_gates_backward(gi, gh, h, g.contiguous())
+        return dgi, dgh, dh
+
+
+def gru_gates(gi, gh, h):
+    return _GruGates.apply(gi, gh, h)
 
 
 class _Linear(torch.autograd.Function):

@@ -120,10 +120,10 @@ class GMNPropagator(nn.Module):
         else:
             csr = merge.csr()
         n, D = x.shape
-        if self.f_node_name == 'GRU':
-            return self._forward_gru(x, csr, merge, model)
         if self.training and torch.is_grad_enabled():
             return self._forward_train(x, csr, merge, model)
+        if self.f_node_name == 'GRU':
+            return self._forward_gru(x, csr, merge, model)
         if self._use_sp(n, D):
             return self._forward_sp(x, csr, merge, model, batch_data)
         with torch.no_grad():
@@ -395,9 +395,7 @@ class GMNPropagator(nn.Module):
     def _forward_gru(self, x, csr, merge, model):
         """f_node='GRU' (model/layers_gmn.py:27-30,48-50; non-default): out = GRUCell(cat(m_sum, u_sum), x).  The
         message sum and the attention as in the MLP variant, the two gate GEMMs through blgnn_linear, the gate
-        arithmetic in one kernel.  Forward only."""
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("blgnn: f_node='GRU' runs forward-only")
+        arithmetic in one kernel (train mode: ``_forward_train``)."""
         n, D = x.shape
         cell = self.f_node
         with torch.no_grad():
@@ -429,7 +427,14 @@ class GMNPropagator(nn.Module):
         deg = ops.row_degree(csr).view(-1, 1)
         m_sum = ag.linear(torch.cat([s, deg], dim=1), torch.cat([lin2.weight, lin2.bias.view(-1, 1)], dim=1), None)
         u = ag.gmn_match(x, merge.segments())
-        out = self.f_node(torch.cat([x, m_sum, u], dim=1))
+        if isinstance(self.f_node, nn.GRUCell):
+            # out = GRUCell(cat(m_sum, u_sum), x): two gate products + the gate arithmetic, each with its backward kernel
+            cell = self.f_node
+            gi = ag.linear(torch.cat([m_sum, u], dim=1), cell.weight_ih, cell.bias_ih)
+            gh = ag.linear(x, cell.weight_hh, cell.bias_hh)
+            out = ag.gru_gates(gi, gh, x)
+        else:
+            out = self.f_node(torch.cat([x, m_sum, u], dim=1))
         model.store_layer_output(self, out)
         return out
 

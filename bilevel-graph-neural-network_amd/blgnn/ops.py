@@ -1074,6 +1074,22 @@ def gru_gates(gi, gh, h, out=None):
     return y
 
 
+def gru_gates_backward(gi, gh, h, g):
+    """-> (dgi [n, 3D], dgh [n, 3D], dh [n, D]) of ``gru_gates`` for the output gradient ``g``."""
+    gip, ldgi = _mat(gi, "gi")
+    ghp, ldgh = _mat(gh, "gh")
+    hp, ldh = _mat(h, "h")
+    gp, ldg = _mat(g, "g")
+    n, D = h.shape
+    if gi.shape != (n, 3 * D) or gh.shape != (n, 3 * D) or g.shape != (n, D):
+        raise ValueError("blgnn: gru_gates_backward expects [n, 3D] gate tables and [n, D] state / gradient")
+    dgi, dgh = torch.empty_like(gi), torch.empty_like(gh)
+    dh = torch.empty((n, D), dtype=torch.float32, device=h.device)
+    call("blgnn_gru_gates_backward", gip, ldgi, ghp, ldgh, hp, ldh, gp, ldg, n, D, dgi.data_ptr(), dgi.stride(0),
+         dgh.data_ptr(), dgh.stride(0), dh.data_ptr(), dh.stride(0), _stream())
+    return dgi, dgh, dh
+
+
 def hadamard(a, b, out=None):
     ap, lda = _mat(a, "a")
     bp, ldb = _mat(b, "b")

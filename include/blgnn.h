@@ -462,6 +462,15 @@ int blgnn_split_rows_sp_pairs(const float *x, int64_t ldx, const int32_t *seg, c
 int blgnn_gru_gates(const float *gi, int64_t ldgi, const float *gh, int64_t ldgh, const float *h,
                     int64_t ldh, int32_t n, int32_t D, float *out, int64_t ldo, void *stream);
 
+/* Backward of blgnn_gru_gates (training GMNPropagator(f_node='GRU'), model/layers_gmn.py:27-30,48-50 under
+ * src/train.py:177-182): from the forward's gate tables gi, gh, the state h and g = d loss / d h' (all [n, .]) ->
+ * dgi, dgh [n, 3D] (gate order r | z | n) and the state's direct share dh = g z [n, D]; the gates are recomputed.
+ * The four products around it (d in = dgi W_ih, dW_ih = dgi^T in, dh += dgh W_hh, dW_hh = dgh^T h) and the bias sums
+ * are blgnn_linear / blgnn_grad_weight / blgnn_col_reduce. */
+int blgnn_gru_gates_backward(const float *gi, int64_t ldgi, const float *gh, int64_t ldgh, const float *h,
+                             int64_t ldh, const float *g, int64_t ldg, int32_t n, int32_t D, float *dgi,
+                             int64_t lddgi, float *dgh, int64_t lddgh, float *dh, int64_t lddh, void *stream);
+
 /* out = a * b elementwise: the gate of GMNAggregatorPairs (model/layers_aggregation.py:88-93: sigmoid(gate) * weight,
  * the sigmoid rides on the producing blgnn_linear's epilogue). */
 int blgnn_hadamard(const float *a, int64_t lda, const float *b, int64_t ldb, int32_t n, int32_t d,

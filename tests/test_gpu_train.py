@@ -574,6 +574,60 @@ def test_mhcaddi_gmn_training_step_gradients(device):
     assert checked >= 3 * 6 + 3 * 10
 
 
+def test_gru_gates_backward(device):
+    """the GRU gate arithmetic (torch.nn.GRUCell) and its backward kernel against fp64 autograd: dgi, dgh, dh"""
+    n, D = 777, 48
+    g = torch.Generator().manual_seed(4)
+    gi, gh, h, dy = (torch.randn(n, 3 * D, generator=g), torch.randn(n, 3 * D, generator=g), torch.randn(n, D, generator=g),
+                     torch.randn(n, D, generator=g))
+    gir, ghr, hr = _leaf(gi), _leaf(gh), _leaf(h)
+    r = torch.sigmoid(gir[:, :D] + ghr[:, :D])
+    z = torch.sigmoid(gir[:, D:2 * D] + ghr[:, D:2 * D])
+    c = torch.tanh(gir[:, 2 * D:] + r * ghr[:, 2 * D:])
+    ref = (1 - z) * c + z * hr
+    ref.backward(dy.double())
+    gid, ghd, hd = _leaf(gi, device), _leaf(gh, device), _leaf(h, device)
+    got = ag.gru_gates(gid, ghd, hd)
+    got.backward(dy.to(device))
+    assert max_err(got, ref) < TOL
+    for a, b in ((gid, gir), (ghd, ghr), (hd, hr)):
+        assert max_err(a.grad, b.grad) < TOL
+
+
+def test_mhcaddi_gmn_gru_training_step_gradients(device):
+    """the GMN model with f_node='GRU' (model/layers_gmn.py:27-30,48-50) under loss.backward(): loss and every
+    parameter gradient (GRUCell weight_ih / weight_hh / bias_ih / bias_hh included) against fp64 autograd on the oracle"""
+    ds = blgnn.make_synthetic(40, 200, seed=6, device=device)
+    flags = blgnn.make_flags("lower_level_gmn", lower_level_gnn_type="gin", D_lower=64, device=device, gmn_f_node="GRU")
+    model, data = build(flags, ds, seed=9)
+    assert isinstance(model.layers[1].f_node, torch.nn.GRUCell)
+    specs = layer_specs(flags)
+    rng = np.random.default_rng(1)
+    pairs = ds.pair_gids[rng.choice(len(ds.pair_gids), size=16, replace=False)]
+    bd = blgnn.BatchData(pairs, ds, sampled_gids=np.unique(pairs), is_train=True, unique_graphs=False,
+                         rng=np.random.default_rng(2))
+    B = len(bd.batch_gids)
+    ids = torch.arange(2 * B).reshape(-1, 2)
+    sd = _oracle_state(model)
+    of = dict(oracle_flags(flags, ds), train=True)
+    acts = oracle.run_layers(specs, sd, plain_batch(bd, ds, torch.float64, with_pairs=ids), of)
+    ref_loss = torch.nn.functional.binary_cross_entropy(acts[-1].view(-1), bd.true_labels().cpu().double())
+    ref_loss.backward()
+    model.train()
+    loss = model(bd)
+    loss.backward()
+    assert max_err(loss, ref_loss) < TOL
+    checked = gru = 0
+    for name, p in model.named_parameters():
+        if name not in sd or not name.startswith("layers.") or sd[name].grad is None:
+            continue
+        assert p.grad is not None, name
+        assert max_err(p.grad, sd[name].grad) < TOL, name
+        checked += 1
+        gru += ".f_node.weight_" in name or ".f_node.bias_" in name
+    assert gru == 3 * 4 and checked >= 3 * 6 + 3 * 4
+
+
 @pytest.mark.parametrize("M,O,I", [(37001, 128, 128), (1, 5, 7), (1025, 130, 40), (2049, 64, 300), (16, 1, 1), (0, 8, 8)])
 def test_grad_weight_and_column_reductions_ragged_shapes(device, M, O, I):
     """the row-chunked weight-gradient reduction and the deterministic column reductions: chunk edges (1 024 / 512
