@@ -515,6 +515,10 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
             for i in range(min(steps, 20)):
                 if not big:
                     torch.mm(blk, blk_w)
+                else:
+                    # launches of milliseconds: no queue blocker needed, but the next step's sweep must not start beside
+                    # this step's interaction pass on the other stream (its events would time the two together)
+                    torch.cuda.synchronize()
                 engine.eager_step(fresh[i % pool])
             torch.cuda.synchronize()
             timer.enabled = gtimer.enabled = False
