@@ -34,6 +34,17 @@ def training_active(module):
     return module.training and torch.is_grad_enabled()
 
 
+def _gemm_transform(M):
+    """The products of ``_Linear`` (y = x W^T and dx = g W): on row counts where the 16-bit matrix-core GEMMs run (the pair
+    batches of the GMN configs: 479 k atoms) the arithmetic the forward path uses -- FLAGS.feature_transform, three fp16 /
+    six bf16 MFMA products per fp32 product, fp32-equivalent --, exact-f32 MFMA below (the interaction level, small
+    batches).  FLAGS.train_exact_gemm = True keeps exact-f32 MFMA everywhere."""
+    from .config import FLAGS
+    if getattr(FLAGS, "train_exact_gemm", False) or M < 32768:
+        return "f32"
+    return None
+
+
 def _check_act(act):
     if act == "prelu":
         raise ValueError("blgnn: a trained PReLU is its own autograd node (autograd.prelu) behind an identity-activation layer")
@@ -99,7 +110,8 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, weight, bias, act):
         _check_act(act)
         w_kn = ops.transpose(weight.detach().contiguous())
-        y = ops.linear(x.detach(), w_kn, None if bias is None else bias.detach(), act=act, transform="f32")
+        y = ops.linear(x.detach(), w_kn, None if bias is None else bias.detach(), act=act,
+                       transform=_gemm_transform(x.shape[0]))
         ctx.act = act
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x.detach(), weight.detach(), y)
@@ -112,7 +124,7 @@ class _Linear(torch.autograd.Function):
         g = dy if ctx.act == "identity" else ops.act_backward(dy, y, ctx.act)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.linear(g, weight.contiguous(), transform="f32")              # [M, out] @ [out, in]
+            dx = ops.linear(g, weight.contiguous(), transform=_gemm_transform(g.shape[0]))   # [M, out] @ [out, in]
         if ctx.needs_input_grad[1]:
             dw = ops.grad_weight(g, x)                                            # sum_m g[m, out] x[m, in]
         if ctx.has_bias and ctx.needs_input_grad[2]:

@@ -261,6 +261,8 @@ class GMNPropagator(nn.Module):
                     ops.split_rows_sp(u, out=u_sp)
 
             n_big = int(order[1][2]) + int(order[1][3])
+            # (resolved HERE, on the launch stream: _side_stream keys on the current stream)
+            side2 = self._side_stream(x.device, 1) if side is not None else None
 
             def fork_match(which="all"):
                 # two side streams: the rarer size classes of the attention (pairs with a graph above 64 nodes: the fp32
@@ -270,7 +272,6 @@ class GMNPropagator(nn.Module):
                 cur = torch.cuda.current_stream(x.device)
                 two = (getattr(FLAGS, "gmn_match_streams", 1) >= 2 or which != "all") and n_big > 0
                 if which in ("all", "big") and two:
-                    side2 = self._side_stream(x.device, 1)
                     side2.wait_stream(cur)
                     with torch.cuda.stream(side2):
                         if match_sp:
@@ -284,10 +285,10 @@ class GMNPropagator(nn.Module):
                 with torch.cuda.stream(side):
                     if two and match_sp:
                         ops.gmn_match_sp(seg, x_planes, u_sp, order, row_map=x_rows, x=x, max_nodes=max_nodes, part="small")
-                        side.wait_stream(self._side_stream(x.device, 1))
+                        side.wait_stream(side2)
                     elif two:
                         ops.gmn_match(seg, x, out=u, max_nodes=max_nodes, classes=1, order=order)
-                        side.wait_stream(self._side_stream(x.device, 1))
+                        side.wait_stream(side2)
                         ops.split_rows_sp(u, out=u_sp)
                     else:
                         match_all()

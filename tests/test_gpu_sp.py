@@ -397,6 +397,31 @@ def test_gmn_sp_pipeline_without_side_stream(device):
     assert preds.shape[0] == 200
 
 
+@pytest.mark.parametrize("fork,streams,match_sp", [("message", 2, True), ("edge", 1, True), ("split", 1, True),
+                                                   ("message", 1, False), ("split", 1, False)])
+def test_gmn_sp_pipeline_attention_placements(device, fork, streams, match_sp):
+    """where and how the attention of the forced sp pipeline runs: forked beside the message GEMM / the edge kernel / the
+    rare size classes beside the GEMM and the common ones beside the edge kernel, on one or two side streams, on the sp
+    planes (blgnn_gmn_match_sp + the fp32 kernels for pairs above 64 nodes) or entirely in fp32 + split -- every variant
+    against the fp64 oracle"""
+    from test_gpu_configs import _gmn_model_vs_oracle
+    import blgnn.config as cfg
+    orig = cfg.make_flags
+
+    def forced(*a, **k):
+        k.setdefault("gmn_sp", "force")
+        f = orig(*a, **k)
+        f.gmn_match_fork, f.gmn_match_streams, f.gmn_match_sp = fork, streams, match_sp
+        return f
+
+    blgnn.make_flags = forced
+    try:
+        preds = _gmn_model_vs_oracle(device, 256, 100, 1200, 200, 77, "drugcombo", 2, "drugcombo")
+    finally:
+        blgnn.make_flags = orig
+    assert preds.shape[0] == 200
+
+
 @pytest.mark.parametrize("sizes,mapped", [
     ([32, 32, 33, 31, 64, 64, 1, 64, 64, 1, 5, 7, 24, 24], False),     # tile edges of both kernels, one-node graphs
     ([40, 38, 2, 60, 17, 9, 28, 0, 0, 13, 8, 8], False),               # an empty graph on either side

@@ -542,6 +542,26 @@ def test_edge_relu_sum_and_gmn_match_backward(device):
     assert max_err(xd.grad, xr.grad) < TOL
 
 
+@pytest.mark.parametrize("D", [256, 512, 72])
+def test_gmn_match_backward_staged_and_global_paths(device, D):
+    """the attention backward with one graph of the pair staged in LDS (graphs up to 64 rows at d = 256, 37 at d = 512)
+    next to pairs that take the global-memory path in the same launch (a larger graph), an empty graph, one-node graphs,
+    a width that is not a multiple of 64 -- dx against fp64 autograd on the oracle"""
+    sizes = [5, 7, 33, 31, 64, 64, 65, 12, 37, 38, 130, 20, 0, 9, 1, 1, 29, 30]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    ind = [(int(off[i]), int(off[i + 1])) for i in range(len(sizes))]
+    g = torch.Generator().manual_seed(D)
+    x, du = torch.randn(int(off[-1]), D, generator=g), torch.randn(int(off[-1]), D, generator=g)
+    xr = _leaf(x)
+    ref = oracle.ops.gmn_match(xr, ind)
+    ref.backward(du.double())
+    xd = _leaf(x, device)
+    got = ag.gmn_match(xd, torch.as_tensor(off, dtype=torch.int32, device=device))
+    got.backward(du.to(device))
+    assert max_err(got, ref) < TOL
+    assert max_err(xd.grad, xr.grad) < TOL
+
+
 def test_mhcaddi_gmn_training_step_gradients(device):
     """the GMN model (lower_level_gmn: GIN + GMNPropagator layers, pair mode) under loss.backward(): loss and every
     parameter gradient against fp64 autograd on the oracle, train-mode BatchNorm in the layers and inside f_node"""
