@@ -398,7 +398,7 @@ def test_gmn_sp_pipeline_without_side_stream(device):
 
 
 @pytest.mark.parametrize("fork,streams,match_sp", [("message", 2, True), ("edge", 1, True), ("split", 1, True),
-                                                   ("message", 1, False), ("split", 1, False)])
+                                                   ("split", 1, False)])
 def test_gmn_sp_pipeline_attention_placements(device, fork, streams, match_sp):
     """where and how the attention of the forced sp pipeline runs: forked beside the message GEMM / the edge kernel / the
     rare size classes beside the GEMM and the common ones beside the edge kernel, on one or two side streams, on the sp
