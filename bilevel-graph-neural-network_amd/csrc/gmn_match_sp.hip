@@ -519,7 +519,8 @@ extern "C" int blgnn_gmn_match_sp(const int32_t *seg, int32_t num_pairs, const v
     BLGNN_CHECK_ARG(x_rows > 0, "gmn_match_sp: x_rows");
     if (row_map && x_rows * ldxs * 2 > 0xfffff000ll)
         return fail(BLGNN_ERR_UNSUPPORTED, "gmn_match_sp: mapped x planes must stay below 4 GiB (32-bit buffer offsets)");
-    if (ldxs * 2 * 128 >= ((int64_t)1 << 31)) return fail(BLGNN_ERR_UNSUPPORTED, "gmn_match_sp: plane rows too long");
+    if (ldxs * 2 * 128 >= ((int64_t)1 << 31) || ldus * 2 * 128 >= ((int64_t)1 << 31))
+        return fail(BLGNN_ERR_UNSUPPORTED, "gmn_match_sp: plane rows too long (32-bit offsets inside a pair)");
     MatchSpArgs A;
     A.seg = seg; A.xs = reinterpret_cast<const _Float16 *>(xs); A.ldxs = ldxs; A.xe = xe; A.ldxe = ldxe;
     A.row_map = row_map; A.x_rows = x_rows;
