@@ -1126,13 +1126,15 @@ def run_train_gmn(args, D, transform, steps, warmup):
         raise SystemExit("bench.py --train: the loss is not finite")
     return {"metric": "DDI edge-pairs/sec (GMN TRAINING step: forward + backward + SGD)", "value": scored / el,
             "unit": "pairs/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * el / steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_OF[transform], "data": "synthetic",
             "config": {"workload": "TRAINING, %s-shape lower-level GMN (GIN + GMNPropagator x3, pair batches), d=%d: %d positive "
                                    "and as many sampled negative pairs per step, a fresh batch (merge, CSR, segments) built on the "
                                    "host inside every timed step" % (cfg["shape"], d, pos_per_step),
                        "baseline_config_index": args.config, "atoms_per_step_mean": float(np.mean(atoms[-steps:])),
                        "optimizer": "SGD(momentum 0.9)", "iteration": "eager (the batch graph changes shape every step)",
-                       "arithmetic": "exact-f32 MFMA products in both directions (blgnn/autograd.py)",
+                       "arithmetic": "y = x W^T and dx = g W on the forward path's fp32-equivalent 16-bit MFMA GEMMs (three fp16 / six bf16 "
+                                     "products per fp32 product), weight gradients and small products on exact-f32 MFMA "
+                                     "(blgnn/autograd.py)",
                        "loss_first3_mean": first, "loss_last3_mean": last}}
 
 
