@@ -469,10 +469,12 @@ __global__ void __launch_bounds__(256) k_split_sp_pairs(const float *__restrict_
                                                         const int32_t *__restrict__ list, int n_list, int KB,
                                                         _Float16 *__restrict__ xs, int64_t ldxs, uint8_t *__restrict__ xe,
                                                         int64_t ldxe) {
+    // grid (pair, part): SPLIT_PARTS workgroups share a pair's (row, block) units -- a pair of this class has 70-300 rows, and
+    // one workgroup walking them four at a time is a chain of ~50 dependent round trips (113 us per launch for 415 pairs)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int pair = list[blockIdx.x];
     const int m0 = seg[2 * pair], m1 = seg[2 * pair + 2];
-    for (int64_t unit = (int64_t)m0 * KB + wid; unit < (int64_t)m1 * KB; unit += 4) {
+    for (int64_t unit = (int64_t)m0 * KB + blockIdx.y * 4 + wid; unit < (int64_t)m1 * KB; unit += 4 * gridDim.y) {
         const int m = (int)(unit / KB), kb = (int)(unit % KB);
         const float4 v = *reinterpret_cast<const float4 *>(x + (int64_t)m * ldx + kb * SP_BLOCK + lane * 4);
         float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
@@ -547,7 +549,7 @@ extern "C" int blgnn_split_rows_sp_pairs(const float *x, int64_t ldx, const int3
     BLGNN_CHECK_ARG(x && seg && pair_list && xs && xe && ldx >= K && ldxs >= 2 * (int64_t)K && ldxe >= K / SP_BLOCK,
                     "split_rows_sp_pairs: bad args");
     BLGNN_CHECK_ARG(ldx % 4 == 0 && aligned16(x) && ldxs % 8 == 0 && aligned16(xs), "split_rows_sp_pairs: 16-byte alignment");
-    hipLaunchKernelGGL(k_split_sp_pairs, dim3(n_list), dim3(256), 0, (hipStream_t)stream, x, ldx, seg, pair_list, n_list,
+    hipLaunchKernelGGL(k_split_sp_pairs, dim3(n_list, 8), dim3(256), 0, (hipStream_t)stream, x, ldx, seg, pair_list, n_list,
                        K / SP_BLOCK, reinterpret_cast<_Float16 *>(xs), ldxs, xe, ldxe);
     return launch_status("split_rows_sp_pairs");
 }

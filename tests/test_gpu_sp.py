@@ -397,6 +397,22 @@ def test_gmn_sp_pipeline_without_side_stream(device):
     assert preds.shape[0] == 200
 
 
+def test_gmn_match_sp_rejects_other_widths_and_aliased_planes(device):
+    """one scale block per row is what the kernel is written for: d = 512 planes are refused (callers keep the fp32
+    kernels), so are result planes aliasing the input's"""
+    sizes = [10, 12, 20, 9]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    ind = [(int(off[i]), int(off[i + 1])) for i in range(len(sizes))]
+    seg = torch.as_tensor(off, dtype=torch.int32, device=device)
+    order = ops.match_pair_order(ind, device)
+    x512 = ops.split_rows_sp(torch.randn(int(off[-1]), 512, device=device))
+    with pytest.raises(NotImplementedError):
+        ops.gmn_match_sp(seg, x512, ops.SpRows(int(off[-1]), 512, device), order)
+    x256 = ops.split_rows_sp(torch.randn(int(off[-1]), 256, device=device))
+    with pytest.raises(ValueError):
+        ops.gmn_match_sp(seg, x256, x256, order)
+
+
 @pytest.mark.parametrize("fork,streams,match_sp", [("message", 2, True), ("edge", 1, True), ("split", 1, True),
                                                    ("split", 1, False)])
 def test_gmn_sp_pipeline_attention_placements(device, fork, streams, match_sp):
