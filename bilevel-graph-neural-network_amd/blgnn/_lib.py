@@ -72,7 +72,7 @@ SIGNATURES = {
     "blgnn_gru_gates": [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p],
     "blgnn_gru_gates_backward": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p],
     "blgnn_gmn_match": [_p, _i32, _p, _i64, _p, _i64, _i32, _p, _i32, _i32, _p, _p, _p],
-    "blgnn_gmn_match_sp": [_p, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _p, _p, _p],
+    "blgnn_gmn_match_sp": [_p, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _p, _p, _i32, _p],
     "blgnn_split_rows_sp_pairs": [_p, _i64, _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p],
     "blgnn_pair_gather_normalize": [_p, _i64, _p, _p, _i32, _i32, _f32, _p, _i64, _p],
     "blgnn_link_pred_head": [_p, _i64, _p, _p, _i32, _i32, _f32, _i32, _p, _p, _p, _i32, _i32, _p, _i64, _p],

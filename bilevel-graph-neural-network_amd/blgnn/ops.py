@@ -714,17 +714,19 @@ def segment_reduce_multi(seg, xs, kind="mean", row_map=None, out=None):
 
 
 def match_pair_order(ind_list, device):
-    """-> (order int32 device tensor, counts int32[4] numpy): the pair indices of a batch grouped by the size of their
-    larger graph (<= 32, <= 64, <= 128, larger), from the host-side list of node ranges (src/merged_graph.py:56-57)."""
+    """-> (order int32 device tensor, counts int32[4] numpy, n_le48): the pair indices of a batch grouped by the size of
+    their larger graph (<= 32, <= 64, <= 128, larger), smaller pairs first inside a class, from the host-side list of node
+    ranges (src/merged_graph.py:56-57); ``n_le48``: how many pairs of the second class have no graph above 48 nodes."""
     import numpy as np
     sizes = ind_list.sizes() if hasattr(ind_list, "sizes") else \
         np.asarray([int(e) - int(s) for s, e in ind_list], dtype=np.int64)
     big = np.maximum(sizes[0::2], sizes[1::2][:len(sizes[0::2])]) if len(sizes) else sizes
     cls = np.where(big <= 0, 4, np.where(big <= 32, 0, np.where(big <= 64, 1, np.where(big <= 128, 2, 3))))
-    order = np.argsort(cls, kind="stable")
+    order = np.lexsort((big, cls))                        # by class, then by size (stable)
     counts = np.bincount(cls, minlength=5)[:4].astype(np.int32)
     order = order[:int(counts.sum())].astype(np.int32)
-    return torch.as_tensor(order).to(device), np.ascontiguousarray(counts)
+    n_le48 = int(np.count_nonzero((cls == 1) & (big <= 48)))
+    return torch.as_tensor(order).to(device), np.ascontiguousarray(counts), n_le48
 
 
 def gmn_match(seg, x, out=None, row_amax=None, max_nodes=0, classes=0, order=None):
@@ -763,7 +765,7 @@ def gmn_match_sp(seg, x_sp, out_sp, order, row_map=None, x=None, max_nodes=0, pa
     if part in ("all", "small"):
         call("blgnn_gmn_match_sp", _vec(seg, "seg", torch.int32, False), G // 2, *_sp_args(x_sp, xr, d),
              _vec(row_map, "row_map", torch.int32), xr, *_sp_args(out_sp, n, d), d,
-             _vec(order[0], "order", torch.int32, False), counts.ctypes.data, _stream())
+             _vec(order[0], "order", torch.int32, False), counts.ctypes.data, int(order[2]) if len(order) > 2 else 0, _stream())
     if n_big and part in ("all", "big"):
         if x is None:
             raise ValueError("blgnn: this batch has pairs above 64 nodes: gmn_match_sp needs the fp32 rows of x for them")

@@ -26,7 +26,7 @@ int main(int argc, char **argv) {
     for (int64_t o = 0; o < n * ld; o += (int64_t)h.size())
         CK(hipMemcpy(xs + o, h.data(), std::min<int64_t>(h.size(), n * ld - o) * 2, hipMemcpyHostToDevice));
     CK(hipMemset(xe, 120, n * 8));
-    auto run = [&]() { return blgnn_gmn_match_sp(dseg, P, xs, ld, xe, 8, nullptr, n, us + 6 * d, ld, ue, 8, d, dord, counts, nullptr); };
+    auto run = [&]() { return blgnn_gmn_match_sp(dseg, P, xs, ld, xe, 8, nullptr, n, us + 6 * d, ld, ue, 8, d, dord, counts, (big > 32 && big <= 48 && !getenv("MSP_R64")) ? P : 0, nullptr); };
     for (int i = 0; i < 3; ++i) if (run()) { printf("rc %s\n", blgnn_last_error()); return 1; }
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

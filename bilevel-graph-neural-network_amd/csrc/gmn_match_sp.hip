@@ -64,7 +64,7 @@ template <int R_> struct MatchSp {
     static constexpr int NST = 3;                          // ring stages: two chunks in flight beside the one being read
     static constexpr int RING = NST * STAGE;
     static constexpr int BYTES = RING + 4 * 64 * 4;        // + inverse norms and scale factors of both graphs' rows:
-    //   R = 64: 50 176 B (three wavefronts per CU), 48: 37 888 B (four), 32: 25 600 B (six)
+    //   R = 64: 50 176 B (three wavefronts per CU), 48: 37 888 B (four: every SIMD has one), 32: 25 600 B (six)
 };
 
 // power of two from a biased exponent field; fields below 1 flush to zero
@@ -115,6 +115,8 @@ __device__ __forceinline__ void msp_pair(const MatchSpArgs &A, char *base, const
     typedef MatchSp<R> W;
     constexpr int GRAPH = W::GRAPH, STAGE = W::STAGE, NST = W::NST, NP = R / 8, NCH = 8, TM = T1 > T2 ? T1 : T2;
     constexpr int TT[2] = {T1, T2};
+    // k steps (16 rows) of tile t that lie inside an R-row image: R = 48 has rows 32 .. 47 of its second tile only
+#define MSP_KS(t) ((R - 32 * (t)) >= 32 ? 2 : 1)
     const int n[2] = {s1 - s0, s2 - s1};
     const int sg[2] = {s0, s1};
     float *arr = reinterpret_cast<float *>(base + W::RING);                    // [4][64]: inverse norms, scale factors x 2 graphs
@@ -208,12 +210,14 @@ __device__ __forceinline__ void msp_pair(const MatchSpArgs &A, char *base, const
         f16x8 a[2][2][TM][2];                                                  // [k step][graph][tile][piece]
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const int slot = (((2 * s + h) ^ fsw) << 4);
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
                 for (int t = 0; t < TT[g]; ++t) {
-                    const int off = g * GRAPH + (32 * t + r) * 128 + slot;
+                    // (R = 48: lanes 16 .. 31 of the second tile would address rows 48 .. 63; they re-read row 47 -- same
+                    // (row >> 1) & 7 as row 63, so the slot holds -- and their scores are masked as rows the graph lacks)
+                    const int row = (32 * t + r) < R ? (32 * t + r) : (R - 1);
+                    const int off = g * GRAPH + row * 128 + ((((2 * s + h) ^ ((row >> 1) & 7))) << 4);
                     a[s][g][t][0] = *reinterpret_cast<const f16x8 *>(st + off);
                     a[s][g][t][1] = *reinterpret_cast<const f16x8 *>(st + (off ^ 64));
                 }
@@ -372,7 +376,7 @@ __device__ __forceinline__ void msp_pair(const MatchSpArgs &A, char *base, const
 #pragma unroll
             for (int t = 0; t < TT[g]; ++t)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
+                for (int s = 0; s < MSP_KS(t); ++s) {
                     const int o0 = g * GRAPH + (32 * t + 16 * s) * 128;
 #pragma unroll
                     for (int pc = 0; pc < 2; ++pc) {
@@ -393,14 +397,14 @@ __device__ __forceinline__ void msp_pair(const MatchSpArgs &A, char *base, const
 #pragma unroll
             for (int k = 0; k < 16; ++k) z[k] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < MSP_KS(to); ++s) {
                 z = __builtin_amdgcn_mfma_f32_32x32x16_f16(Xt[d][to][s][0], Df[d][to][s], z, 0, 0, 0);
                 z = __builtin_amdgcn_mfma_f32_32x32x16_f16(Xt[d][to][s][1], Df[d][to][s], z, 0, 0, 0);
             }
 #pragma unroll
             for (int tp = 0; tp < TT[gp]; ++tp)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
+                for (int s = 0; s < MSP_KS(tp); ++s) {
                     z = __builtin_amdgcn_mfma_f32_32x32x16_f16(Xt[gp][tp][s][0], Ef[d][to][tp][s][0], z, 0, 0, 0);
                     z = __builtin_amdgcn_mfma_f32_32x32x16_f16(Xt[gp][tp][s][1], Ef[d][to][tp][s][0], z, 0, 0, 0);
                     z = __builtin_amdgcn_mfma_f32_32x32x16_f16(Xt[gp][tp][s][0], Ef[d][to][tp][s][1], z, 0, 0, 0);
@@ -508,7 +512,7 @@ using namespace blgnn;
 extern "C" int blgnn_gmn_match_sp(const int32_t *seg, int32_t num_pairs, const void *xs, int64_t ldxs, const uint8_t *xe,
                                   int64_t ldxe, const int32_t *row_map, int64_t x_rows, void *us, int64_t ldus, uint8_t *ue,
                                   int64_t ldue, int32_t d, const int32_t *pair_order, const int32_t *class_counts_host,
-                                  void *stream) {
+                                  int32_t n_le48, void *stream) {
     BLGNN_CHECK_ARG(num_pairs >= 0, "gmn_match_sp: negative size");
     if (num_pairs == 0) return BLGNN_OK;
     if (d != SP_BLOCK) return fail(BLGNN_ERR_UNSUPPORTED, "gmn_match_sp: d = %d (one 256-column scale block per row); use blgnn_gmn_match", d);
@@ -519,6 +523,7 @@ extern "C" int blgnn_gmn_match_sp(const int32_t *seg, int32_t num_pairs, const v
     BLGNN_CHECK_ARG(class_counts_host[0] >= 0 && class_counts_host[1] >= 0 &&
                     (int64_t)class_counts_host[0] + class_counts_host[1] <= num_pairs, "gmn_match_sp: bad class counts");
     BLGNN_CHECK_ARG(x_rows > 0, "gmn_match_sp: x_rows");
+    BLGNN_CHECK_ARG(n_le48 >= 0 && n_le48 <= class_counts_host[1], "gmn_match_sp: n_le48 exceeds the <= 64-node class");
     if (row_map && x_rows * ldxs * 2 > 0xfffff000ll)
         return fail(BLGNN_ERR_UNSUPPORTED, "gmn_match_sp: mapped x planes must stay below 4 GiB (32-bit buffer offsets)");
     if (ldxs * 2 * 128 >= ((int64_t)1 << 31) || ldus * 2 * 128 >= ((int64_t)1 << 31))
@@ -534,8 +539,15 @@ extern "C" int blgnn_gmn_match_sp(const int32_t *seg, int32_t num_pairs, const v
         rc = row_map ? launch_match_sp<32, true>(A, s) : launch_match_sp<32, false>(A, s);
         if (rc != BLGNN_OK) return rc;
     }
-    if (class_counts_host[1] > 0) {
-        A.list = pair_order + class_counts_host[0]; A.n_list = class_counts_host[1];
+    // the <= 64-node class: its first n_le48 listed pairs (both graphs <= 48 nodes) with 48-row chunk images -- 37 KB of
+    // LDS, four wavefronts per CU instead of three --, the rest with 64-row images
+    if (n_le48 > 0) {
+        A.list = pair_order + class_counts_host[0]; A.n_list = n_le48;
+        rc = row_map ? launch_match_sp<48, true>(A, s) : launch_match_sp<48, false>(A, s);
+        if (rc != BLGNN_OK) return rc;
+    }
+    if (class_counts_host[1] > n_le48) {
+        A.list = pair_order + class_counts_host[0] + n_le48; A.n_list = class_counts_host[1] - n_le48;
         rc = row_map ? launch_match_sp<64, true>(A, s) : launch_match_sp<64, false>(A, s);
     }
     return rc;

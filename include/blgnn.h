@@ -444,11 +444,13 @@ int blgnn_gmn_match(const int32_t *seg, int32_t num_pairs, const float *x,
  * processed, the pairs of classes 2 and 3 are the caller's to run through blgnn_gmn_match(classes = 6) +
  * blgnn_split_rows_sp_pairs.  row_map (optional, device int32 [merged atoms]): x plane row of every merged atom (the
  * shared prefix of a pair batch keeps x on the distinct molecules: blgnn_expand_rows' map); x_rows = rows of the x
- * planes.  The result row's scale is a bound (2 * max(own row's scale, largest partner scale)), not its maximum. */
+ * planes.  n_le48: how many of the class-1 pairs, listed first, have both graphs <= 48 nodes (0 = unknown): they run with
+ * 48-row chunk images, four instead of three wavefronts per CU.  The result row's scale is a bound (2 * max(own row's
+ * scale, largest partner scale)), not its maximum. */
 int blgnn_gmn_match_sp(const int32_t *seg, int32_t num_pairs, const void *xs, int64_t ldxs, const uint8_t *xe,
                        int64_t ldxe, const int32_t *row_map, int64_t x_rows, void *us, int64_t ldus,
                        uint8_t *ue, int64_t ldue, int32_t d, const int32_t *pair_order,
-                       const int32_t *class_counts_host, void *stream);
+                       const int32_t *class_counts_host, int32_t n_le48, void *stream);
 
 /* blgnn_split_rows_sp for the rows of the listed pairs only (pair k = rows seg[2k] .. seg[2k + 2]): the pairs the
  * fp32 attention kernels took when the others went through blgnn_gmn_match_sp. */
