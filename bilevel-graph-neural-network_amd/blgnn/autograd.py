@@ -25,7 +25,7 @@ import torch
 
 from . import ops
 
-__all__ = ["linear", "prelu", "gru_gates", "gat_conv", "gcn_conv", "multi_edge_gat", "edge_relu_sum", "gmn_match", "spmm_sum", "batch_norm_train", "segment_reduce_multi", "l2_normalize", "pair_gather",
+__all__ = ["linear", "prelu", "gru_gates", "gat_conv", "gcn_conv", "multi_edge_gat", "multi_edge_gcn", "hadamard", "edge_relu_sum", "gmn_match", "spmm_sum", "batch_norm_train", "segment_reduce_multi", "l2_normalize", "pair_gather",
            "training_active", "set_batch_norm_sync"]
 
 
@@ -249,6 +249,76 @@ def multi_edge_gat(x, convs, csrs, group="src", slope=0.2, act="identity"):
     for c in convs:
         params += [c.weight, c.att, c.bias]
     return _MultiEdgeGat.apply(x, list(csrs), group, slope, act, *params)
+
+
+class _MultiEdgeGcn(torch.autograd.Function):
+    """y = act( sum_k GCNConv_k(x, edges_k) ): NodeModelAggrByEdge('gcn') (model/layers_meta.py:68,74-79).
+    params = (weight_0, bias_0, weight_1, ...), weights in GCNConv's [in, out] layout.  Every A_hat_k is symmetric, so
+    each edge type's propagation is its own gradient operator."""
+
+    @staticmethod
+    def forward(ctx, x, csrs, act, *params):
+        _check_act(act)
+        x = x.detach()
+        K = len(csrs)
+        for c in csrs:
+            c.require_symmetric("multi-edge GCN backward")
+        y = None
+        for k in range(K):
+            w, b = (p.detach() for p in params[2 * k:2 * k + 2])
+            # every edge type accumulates into the same buffer; the activation rides on the last pass
+            y = ops.gcn_conv(csrs[k], x, w, b, None, act=act if k == K - 1 else "identity", out=y, accumulate=k > 0)
+        ctx.csrs, ctx.act, ctx.K = csrs, act, K
+        ctx.save_for_backward(x, y, *[p.detach() for p in params[0::2]])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors[:2]
+        ws = ctx.saved_tensors[2:]
+        dy = dy.contiguous()
+        g = dy if ctx.act == "identity" else ops.act_backward(dy, y, ctx.act)
+        db = ops.col_reduce(g, "sum")                                     # every edge type's bias sees the same g
+        grads, dhs, wts = [], [], []
+        for k in range(ctx.K):
+            dh = ops.gcn_propagate(ctx.csrs[k], g)
+            grads += [ops.grad_weight(x, dh), db]
+            dhs.append(dh)
+            wts.append(ops.transpose(ws[k].contiguous()))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # sum_k dh_k W_k^T as ONE product over the concatenated inner dimension
+            dx = ops.linear(torch.cat(dhs, dim=1), torch.cat(wts, dim=0), transform="f32")
+        return (dx, None, None) + tuple(grads)
+
+
+def multi_edge_gcn(x, convs, csrs, act="identity"):
+    params = []
+    for c in convs:
+        params += [c.weight, c.bias]
+    return _MultiEdgeGcn.apply(x, list(csrs), act, *params)
+
+
+class _Hadamard(torch.autograd.Function):
+    """y = a * b, element by element: the gate of GMNAggregatorPairs (model/layers_aggregation.py:91-93) and the
+    'dot_product' pair scorer (model/layers_link_pred.py:65-66)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.detach(), b.detach()
+        ctx.save_for_backward(a, b)
+        return ops.hadamard(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        dy = dy.contiguous()
+        return (ops.hadamard(dy, b) if ctx.needs_input_grad[0] else None,
+                ops.hadamard(dy, a) if ctx.needs_input_grad[1] else None)
+
+
+def hadamard(a, b):
+    return _Hadamard.apply(a, b)
 
 
 class _SpmmSum(torch.autograd.Function):

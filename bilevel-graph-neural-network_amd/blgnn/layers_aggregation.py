@@ -55,8 +55,15 @@ class NodeAggregationPairs(nn.Module):
         ops.require_device(ins, "ins")
         seg = _segments(batch_data, pair_batch)
         if ag.training_active(self) and ins.requires_grad:
-            if not isinstance(self.agg_func, _SegmentPool) or out is not None:
-                raise NotImplementedError("blgnn: training covers the avg_pool / sum readouts of the lower-level model")
+            if out is not None:
+                raise NotImplementedError("blgnn: train mode does not write into a caller-provided slice")
+            if not isinstance(self.agg_func, _SegmentPool):
+                # 'deepsets' / 'gmn_aggr' (model/layers_aggregation.py:45-56,78-95): MLPs and reductions as autograd nodes
+                if self.concat_multi_scale:
+                    xs = model.acts[1:] if 'gmn' not in FLAGS.model else \
+                        [x for i, x in enumerate(model.acts[1:]) if i % 2 == 1]
+                    return torch.cat([self.agg_func(x, seg) for x in xs], dim=1)     # (placement: data movement only)
+                return self.agg_func(ins, seg)
             if self.concat_multi_scale:
                 xs = model.acts[1:] if 'gmn' not in FLAGS.model else \
                     [x for i, x in enumerate(model.acts[1:]) if i % 2 == 1]
@@ -142,6 +149,8 @@ class DeepSets(nn.Module):
         self.rho = MLP(out_dim, out_dim, num_hidden_lyr=num_mlp_layers - 1)
 
     def forward(self, ins, seg, out=None):
+        if ag.training_active(self) and ins.requires_grad:
+            return self.rho(ag.segment_reduce_multi(seg, [self.phi(ins)], "mean"))
         return self.rho(ops.segment_reduce(seg, self.phi(ins), "mean"), out=out)
 
 
@@ -230,6 +239,10 @@ class GMNAggregatorPairs(nn.Module):
                              hidden_channels=[output_dim], bn=bn)
 
     def forward(self, x, seg, out=None):
+        if ag.training_active(self) and x.requires_grad:
+            # training: the three MLPs (train-mode BatchNorm inside), the gate product and the sum as autograd nodes
+            gated_x = self.gate_func(x, final_act="sigmoid")
+            return self.mlp_graph(ag.segment_reduce_multi(seg, [ag.hadamard(gated_x, self.weight_func(x))], "sum"))
         weighted_x = self.weight_func(x)
         gated_x = self.gate_func(x, final_act="sigmoid")                # the sigmoid rides on the last GEMM's epilogue
         graph_embeddings = ops.segment_reduce(seg, ops.hadamard(gated_x, weighted_x), "sum")

@@ -82,10 +82,15 @@ class LinkPred(nn.Module):
         ids1, ids2 = ids
         mlp = getattr(self, "mlp_concat", None)
         if ag.training_active(self) and ins.requires_grad:
-            if self.type != "mlp_concat":
-                raise NotImplementedError("blgnn: training covers the mlp_concat pair scorer")
             cat = ag.pair_gather(ag.l2_normalize(ins), ids1, ids2)
-            pair_preds = self.mlp_concat(cat, final_act="identity" if self.multi_label_pred else "sigmoid")
+            if self.type == "mlp_concat":
+                pair_preds = self.mlp_concat(cat, final_act="identity" if self.multi_label_pred else "sigmoid")
+            else:
+                # 'dot_product' (model/layers_link_pred.py:65-66): sigmoid(<z1, z2>) = product node + a [1, d] row of
+                # ones as the Linear's (constant) weight, the sigmoid on its epilogue
+                d = ins.shape[1]
+                ones = torch.ones((1, d), dtype=torch.float32, device=ins.device)
+                pair_preds = ag.linear(ag.hadamard(cat[:, :d], cat[:, d:]), ones, None, "sigmoid").view(-1)
             batch_data.pair_preds = pair_preds
             return pair_preds
         with torch.no_grad():

@@ -93,7 +93,10 @@ class MetaLayerWrapper(nn.Module):
                                      group=getattr(FLAGS, "gat_softmax_group", "src"),
                                      slope=self.node_model.GNNS[0].negative_slope, act=act_name(self.activation))
         if ag.training_active(self):
-            raise NotImplementedError("blgnn: training covers the 'gat_multi_edge_aggr' node model")
+            # 'gcn_multi_edge_aggr' (model/layers_meta.py:68,74-79): sum over edge types of GCNConv + act as one node
+            graphs = list(batch_data.merge_higher_level['edges'].values())
+            return ag.multi_edge_gcn(ins, list(self.node_model.GNNS)[:len(graphs)], [g.csr() for g in graphs],
+                                     act=act_name(self.activation))
         with torch.no_grad():
             return self.node_model(ins, merge.edge_index, merge.edge_attr, batch_data,
                                    final_act=act_name(self.activation))

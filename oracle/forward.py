@@ -110,7 +110,7 @@ def _aggregation(x, info, sd, p, plain, flags, acts):
         out = ops.gmn_aggregator(x, batch, G,
                                  _mlp_params(sd, p + ".agg_func.weight_func"),
                                  _mlp_params(sd, p + ".agg_func.gate_func"),
-                                 _mlp_params(sd, p + ".agg_func.mlp_graph"))
+                                 _mlp_params(sd, p + ".agg_func.mlp_graph"), train=bool(flags.get("train")))
     else:
         raise NotImplementedError("{} is not implemented".format(style))
     if flags.get("higher_level_layers") and plain.get("graph_rows") is not None:

@@ -283,12 +283,12 @@ def deepsets(x, batch, num_graphs, phi, rho):
     return mlp(scatter_mean(mlp(x, phi), batch, num_graphs), rho)
 
 
-def gmn_aggregator(x, batch, num_graphs, weight_f, gate_f, graph_f):
-    """model/layers_aggregation.py:78-95; each arg = (linears, bns)."""
-    wx = mlp(x, weight_f[0], "relu", weight_f[1])
-    gx = torch.sigmoid(mlp(x, gate_f[0], "relu", gate_f[1]))
+def gmn_aggregator(x, batch, num_graphs, weight_f, gate_f, graph_f, train=False):
+    """model/layers_aggregation.py:78-95; each arg = (linears, bns); ``train``: batch statistics in the MLPs' BN."""
+    wx = mlp(x, weight_f[0], "relu", weight_f[1], train)
+    gx = torch.sigmoid(mlp(x, gate_f[0], "relu", gate_f[1], train))
     ge = scatter_add(gx * wx, batch, num_graphs)
-    return mlp(ge, graph_f[0], "relu", graph_f[1])
+    return mlp(ge, graph_f[0], "relu", graph_f[1], train)
 
 
 def node_aggregation(acts, batch, num_graphs, style="avg_pool"):

@@ -846,3 +846,134 @@ def test_train_step_drugcombo_bilevel_captured_equals_eager(device):
         if s0[k].is_floating_point():
             a, b = s0[k].double().cpu(), s1[k].double().cpu()
             assert float((a - b).abs().max()) / max(1.0, float(a.abs().max())) < 1e-3, k
+
+
+@pytest.mark.parametrize("node_aggr", ["deepsets", "gmn_aggr"])
+def test_llgnn_training_step_gradients_learned_readouts(device, node_aggr):
+    """the DeepSets and gated GMN readouts train (model/layers_aggregation.py:45-56,78-95): loss, every activation and
+    every parameter gradient (the readout's MLPs and, for gmn_aggr, their train-mode BatchNorms included) against fp64
+    autograd on the oracle"""
+    ds = blgnn.make_synthetic(60, 400, seed=5, device=device)
+    flags = blgnn.make_flags("lower_level_gnn", lower_level_gnn_type="gin", D_lower=64, device=device,
+                             node_aggr=node_aggr)
+    model, data = build(flags, ds, seed=7)
+    specs = layer_specs(flags)
+    rng = np.random.default_rng(5)
+    pairs = ds.pair_gids[rng.choice(len(ds.pair_gids), size=48, replace=False)]
+    bd = blgnn.BatchData(pairs, ds, sampled_gids=np.unique(pairs), is_train=True, rng=np.random.default_rng(5))
+    ids = torch.as_tensor(np.vectorize(bd.merge_data['gids_to_batch_ind'].get)(bd.batch_gids))
+    of = oracle_flags(flags, ds)
+    sd = _oracle_state(model)
+    labels = bd.true_labels().cpu().double()
+    ref_loss, acts = _oracle_loss(specs, sd, plain_batch(bd, ds, torch.float64, with_pairs=ids), of, labels)
+    ref_loss.backward()
+
+    model.train()
+    loss = model(bd)
+    assert loss.requires_grad
+    loss.backward()
+    assert max_err(loss, ref_loss) < TOL
+    for got, ref in zip(model.acts[1:-1], acts[1:]):
+        assert max_err(got, ref) < TOL
+    readout = [n for n, _ in model.named_parameters() if ".agg_func." in n]
+    assert len(readout) >= (8 if node_aggr == "deepsets" else 18)
+    checked = 0
+    for name, p in model.named_parameters():
+        if name not in sd or not name.startswith("layers."):
+            continue
+        assert p.grad is not None, name
+        assert max_err(p.grad, sd[name].grad) < TOL, name
+        checked += 1
+    assert checked >= 5 * 6 + 4 + len(readout)
+
+
+def test_multi_edge_gcn_backward(device):
+    """NodeModelAggrByEdge('gcn') (model/layers_meta.py:68,74-79): act(sum_k GCNConv_k(x, edges_k)), forward and every
+    gradient against fp64 autograd on the oracle; and through MetaLayerWrapper in train mode"""
+    import types
+    from test_gpu_ops import rand_graph
+    from blgnn.layers import GCNConv
+    n, K, d = 350, 48, 64
+    eis = [rand_graph(n, deg, seed=s, self_loops=False, isolated=2) for deg, s in ((5, 3), (9, 4), (2, 5))]
+    g = torch.Generator().manual_seed(6)
+    x, dy = torch.randn(n, K, generator=g), torch.randn(n, d, generator=g)
+    convs = [GCNConv(K, d).to(device) for _ in eis]
+    with torch.no_grad():
+        for c in convs:
+            c.bias.copy_(torch.randn(d, generator=g))
+    xr = _leaf(x)
+    pr = [(_leaf(c.weight.detach().cpu()), _leaf(c.bias.detach().cpu())) for c in convs]
+    ref = torch.tanh(sum(oracle.ops.gcn_conv(xr, ei, w, b) for ei, (w, b) in zip(eis, pr)))
+    ref.backward(dy.double())
+    xd = _leaf(x, device)
+    csrs = [ops.csr_from_edge_index(ei.to(device), n) for ei in eis]
+    got = ag.multi_edge_gcn(xd, convs, csrs, act="tanh")
+    got.backward(dy.to(device))
+    assert max_err(got, ref) < TOL
+    assert max_err(xd.grad, xr.grad) < TOL
+    for c, (w, b) in zip(convs, pr):
+        assert max_err(c.weight.grad, w.grad) < TOL
+        assert max_err(c.bias.grad, b.grad) < TOL
+
+
+def test_drugcombo_gcn_multi_edge_training_gradients(device):
+    """the DrugCombo bi-level model with node_model='gcn_multi_edge_aggr' trains: gradients of a linear functional of
+    the logits w.r.t. every parameter against the oracle (the 'gat' twin: test_drugcombo_bignn_training_gradients)"""
+    from blgnn.forward import get_initial_embd, all_molecule_pairs
+    ds = blgnn.make_synthetic(70, 500, seed=8, device=device, num_edge_types=2, name="drugcombo_syn")
+    flags = blgnn.make_flags("lower_level_gnn_higher_level", dataset="drugcombo", lower_level_gnn_type="gin",
+                             device=device, multi_edge_node_model="gcn")
+    model, data = build(flags, ds, seed=11, num_hyper_edge_feat=3)
+    specs = layer_specs(flags)
+    rng = np.random.default_rng(5)
+    pairs = ds.pair_gids[rng.choice(len(ds.pair_gids), size=32, replace=False)]
+    model.train()
+    get_initial_embd(data, model)
+    ds.init_interaction_graph_embds(device)
+    bd = blgnn.BatchData(pairs, ds, is_train=False)
+    model.use_layers = 'higher_layers'
+    model.acts = [bd.merge_data['merge'].x]
+    for layer in model._selected()[:-1]:
+        model.acts.append(layer(model.acts[-1], bd, model))
+    logits = model.acts[-1]
+    assert logits.shape == (32, 3) and logits.requires_grad
+    wgt = torch.randn(32, 3, generator=torch.Generator().manual_seed(0))
+    (logits * wgt.to(device)).sum().backward()
+
+    lower_b = blgnn.BatchData(all_molecule_pairs(ds.gs_map.keys()), ds, is_train=False, ignore_pairs=True)
+    ids = torch.as_tensor(np.vectorize(ds.gs_map.get)(bd.batch_gids))
+    sd = _oracle_state(model)
+    acts = oracle.run_layers(specs, sd, plain_batch(lower_b, ds, torch.float64, with_pairs=ids),
+                             dict(oracle_flags(flags, ds), train=True))
+    assert max_err(logits, acts[-1]) < TOL
+    (acts[-1] * wgt.double()).sum().backward()
+    checked = 0
+    for name, p in model.named_parameters():
+        if name not in sd or not name.startswith("layers.") or sd[name].grad is None:
+            continue
+        assert p.grad is not None, name
+        assert max_err(p.grad, sd[name].grad) < TOL, name
+        checked += 1
+    assert checked >= 30 + 3 * 2 * 2
+
+
+def test_link_pred_dot_product_trains(device):
+    """LinkPred(type='dot_product') (model/layers_link_pred.py:65-66) in train mode: scores and the gradient w.r.t. the
+    graph embeddings against fp64 autograd on the oracle"""
+    import types
+    from blgnn.layers_link_pred import LinkPred
+    g = torch.Generator().manual_seed(4)
+    z = torch.randn(90, 96, generator=g)
+    ids = torch.randint(0, 90, (300, 2), generator=g)
+    wgt = torch.randn(300, generator=g)
+    zr = _leaf(z)
+    ref = oracle.link_pred(zr, ids[:, 0], ids[:, 1], None, "dot_product")
+    (ref.view(-1) * wgt.double()).sum().backward()
+    lp = LinkPred("dot_product", 96, 1).train()
+    bd = types.SimpleNamespace(_pair_row_ids=(ids[:, 0].contiguous().to(device), ids[:, 1].contiguous().to(device)))
+    zd = _leaf(z, device)
+    got = lp(zd, bd, None)
+    assert got.requires_grad
+    (got.view(-1) * wgt.to(device)).sum().backward()
+    assert max_err(got.view(-1), ref.view(-1)) < TOL
+    assert max_err(zd.grad, zr.grad) < TOL
