@@ -86,6 +86,9 @@ def parse():
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the extras: configs[1] summary and the d=256 SpMM/readout micro-roofline")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-shard-upper", action="store_true",
+                    help="N > 1, >= 32 768 interaction rows: keep the interaction level replicated on every rank instead of "
+                         "target-row sharded (blgnn/engine.py shard_upper)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="profiling aid: build rank 0's share of an N-GPU run on one GPU (no collective)")
     ap.add_argument("--fuse-lower", action="store_true",
@@ -468,7 +471,9 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
                            fuse_lower=(False if args.no_fuse_lower else (True if args.fuse_lower else None)),
                            readout_with_upper=args.readout_with_upper,
                            lower_cus_per_xcd=lower_cus, exchange_transformed=(True if emu else None),
-                           prune_last=(True if (emu and not args.no_prune_last) else (False if args.no_prune_last else None)))
+                           prune_last=(True if (emu and not args.no_prune_last) else (False if args.no_prune_last else None)),
+                           shard_upper=(False if args.no_shard_upper else
+                                        (True if (emu and ds.num_graphs() >= 32768) else None)))
     try:
         engine.capture()
         # a fresh random batch of pair ids every step (src/sampler.py:120-131), drawn ahead of the timed
@@ -492,10 +497,12 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
             engine.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for _ in range(3):
-                engine.g_upper[0].replay()
+                for g_ in engine.g_upper[0]:           # (shard_upper: the pass's pieces, without the all-gathers between them)
+                    g_.replay()
             e0.record()
             for _ in range(20):
-                engine.g_upper[0].replay()
+                for g_ in engine.g_upper[0]:
+                    g_.replay()
             e1.record()
             torch.cuda.synchronize()
             upper_ms = e0.elapsed_time(e1) / 20
@@ -540,7 +547,11 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
                       "exchange": ("first interaction layer's transform of the pooled rows [N_r, d+2]"
                                    if engine.exchange_transformed else "pooled rows [N_r, D_pool]"),
                       "interaction_level_ms": upper_ms,
-                      "parallelism": "molecule shards x%d + all-gather(pooled) + pair shards" % world}}
+                      "interaction_level": ("target-row sharded: %d pieces, an all-gather of the next layer's transformed rows "
+                                            "between them" % engine.n_upper_segments) if engine.shard_upper else "replicated",
+                      "parallelism": ("molecule shards x%d + all-gather(pooled) + pair shards" % world) if not engine.shard_upper
+                      else ("molecule shards x%d + interaction target-row shards, %d all-gathers + pair shards"
+                            % (world, engine.n_upper_segments))}}
     if want_roofline and rank == 0:
         ms, work, names = timer.result()
         if "stack" in names:

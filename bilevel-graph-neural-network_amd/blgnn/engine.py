@@ -134,7 +134,7 @@ class BiLevelEngine(object):
 
     def __init__(self, model, lower_batch, upper_batches, graph, sharded=None, world_size=1,
                  use_graph=True, overlap=True, fuse_lower=None, readout_with_upper=None, lower_cus_per_xcd=None,
-                 exchange_transformed=None, prune_last=None, parity_streams=False, serialize=None):
+                 exchange_transformed=None, prune_last=None, parity_streams=False, serialize=None, shard_upper=None):
         from .config import FLAGS
         k = FLAGS.last_lower_lyr_num
         self.model = model
@@ -247,6 +247,34 @@ class BiLevelEngine(object):
                           "recv": [torch.empty((len(counts) * cmax, D), dtype=torch.float32, device=dev)
                                    for _ in range(self.parities)],
                           "rows": torch.as_tensor(src).to(dev), "even": all(c == cmax for c in counts)}
+        # Target-row sharding of the interaction level (``shard_upper``; needs ``exchange_transformed``).  Replicated, the
+        # graph halves of the interaction layers cost the same ~2 ms on every rank of configs[3] whatever N is, which caps
+        # the 1 -> 8 ratio below 6x (profiles/r04_cfg3_emulated_ranks.txt).  Sharded, a rank runs every layer but the last
+        # on ITS OWN target rows only (softmax statistics stay replicated: 4 B per edge), applies the next layer's row-wise
+        # half to them and all-gathers [N_r, d + 2] again: L - 1 more all-gathers of N x (d + 2) x 4 B per step (102 MB at
+        # configs[3]) in exchange for (N - 1) / N of L - 1 gathers; the last layer computes the rows its pairs read from
+        # the full table (``prune_last``).  Default: N > 1 and >= 32 768 interaction rows (below that the extra
+        # collectives' launch latency is the same size as the compute they save: configs[1]).
+        chain = self.upper_layers[1:-1]
+        can_shard = (self.exchange_transformed and len(chain) >= 2 and
+                     all(isinstance(l, NodeEmbedding) and l.type == 'gat' and l.higher_level and not l.normalize
+                         for l in chain))
+        if shard_upper is None:
+            shard_upper = (self.world > 1 and base.shape[0] >= 32768
+                           and os.environ.get("BLGNN_ENGINE_SHARD_UPPER", "1") != "0")
+        self.shard_upper = bool(shard_upper and can_shard)
+        self.h_more, self._xchg_more, self.own_rows = [], [], None
+        if self.shard_upper:
+            n_all, cmax, nblk = base.shape[0], self._xchg["send"][0].shape[0], self._xchg["recv"][0].shape[0]
+            self.own_rows = torch.arange(self.local_lo, self.local_hi, dtype=torch.int64, device=dev)
+            for layer in chain[1:]:
+                D = layer.out_dim + 4
+                self.h_more.append([torch.zeros((n_all, D), dtype=torch.float32, device=dev) for _ in range(self.parities)])
+                self._xchg_more.append({"send": [torch.zeros((cmax, D), dtype=torch.float32, device=dev)
+                                                 for _ in range(self.parities)],
+                                        "recv": [torch.empty((nblk, D), dtype=torch.float32, device=dev)
+                                                 for _ in range(self.parities)]})
+        self.n_upper_segments = len(chain) if self.shard_upper else 1
         # Pinned-memory copies leave events of torch's host allocator on the stream they ran on; those must
         # never sit on a stream this engine destroys (close()), so the id copies run on an ordinary side
         # stream and the interaction-level stream waits for an event.
@@ -345,14 +373,19 @@ class BiLevelEngine(object):
         send[:rows, d:d + 2].copy_(sc.t())                     # the two scores ride in columns d, d + 1
         return send[:rows]
 
-    def exchange(self, pooled, parity=0):
-        """The one collective of the path: all-gather of the pooled drug rows (padded to the largest
-        shard) into persistent buffers, then ONE row gather that drops the padding into init_x."""
+    def exchange(self, pooled, parity=0, stage=0):
+        """The collective of the path: all-gather of the pooled drug rows (padded to the largest
+        shard) into persistent buffers, then ONE row gather that drops the padding into init_x.  ``stage`` > 0
+        (``shard_upper``): the same for the rows a rank has produced for interaction layer ``stage + 1``."""
         if self.world <= 1 and not self.exchange_transformed:
             return
         x = self._xchg
-        send, recv = x["send"][parity], x["recv"][parity]
-        dest = self.h_full[parity] if self.exchange_transformed else self.init_x[parity]
+        if stage > 0:
+            more = self._xchg_more[stage - 1]
+            send, recv, dest = more["send"][parity], more["recv"][parity], self.h_more[stage - 1][parity]
+        else:
+            send, recv = x["send"][parity], x["recv"][parity]
+            dest = self.h_full[parity] if self.exchange_transformed else self.init_x[parity]
         if not self.exchange_transformed:
             send[:pooled.shape[0]].copy_(pooled)               # (transformed rows were written into ``send``)
         if self.world > 1:
@@ -367,8 +400,19 @@ class BiLevelEngine(object):
         else:
             torch.index_select(recv, 0, x["rows"], out=dest)
 
-    def upper(self, parity=0, readout=False):
-        """Interaction-level layers + pair scorer on the rows in ``ids_dev[parity]``."""
+    def upper(self, parity=0, readout=False, segment=None):
+        """Interaction-level layers + pair scorer on the rows in ``ids_dev[parity]``.  With ``shard_upper`` the pass is
+        ``n_upper_segments`` pieces with an all-gather between consecutive ones: ``segment`` = which piece to enqueue
+        (what a captured graph holds), None = all of them with their exchanges (eager)."""
+        if self.shard_upper:
+            if segment is not None:
+                return self._upper_segment(parity, segment, readout)
+            out = None
+            for k in range(self.n_upper_segments):
+                out = self._upper_segment(parity, k, readout)
+                if k < self.n_upper_segments - 1:
+                    self.exchange(None, parity, stage=k + 1)
+            return out
         self.graph.init_x = self.init_x[parity]
         with torch.no_grad():
             m, b = self.model, self.template
@@ -391,13 +435,52 @@ class BiLevelEngine(object):
             for layer in layers:
                 if layer is prune:
                     # the last interaction-level layer feeds only the pair scorer: compute the rows it reads
-                    layer._out_rows = self.ids_dev[parity].view(-1)
+                    layer._out_rows = self._scored_rows(parity)
                 try:
                     m.acts.append(layer(m.acts[-1], b, m))
                 finally:
                     if layer is prune:
                         layer._out_rows = None
             return m.acts[-1]
+
+    def _upper_segment(self, parity, k, readout=False):
+        """Piece ``k`` of the target-row-sharded interaction pass: the graph half of interaction layer k + 1 on the gathered
+        table of its transformed rows -- on this rank's own target rows, followed by the next layer's row-wise half on
+        them (written into that stage's send block); the last piece computes the rows the scored pairs read and scores."""
+        self.graph.init_x = self.init_x[parity]
+        with torch.no_grad():
+            m, b = self.model, self.template
+            chain, lo, hi = self.upper_layers[1:-1], self.local_lo, self.local_hi
+            if k == 0:
+                b._pair_row_ids = (self.ids_dev[parity][0], self.ids_dev[parity][1])
+                m.acts = [b.merge_data['merge'].x]
+                m.acts.append(self.upper_layers[0](m.acts[-1], b, m))       # LoadInteraction (cached CSR)
+            layer = chain[k]
+            hf = self.h_full[parity] if k == 0 else self.h_more[k - 1][parity]
+            d = layer.out_dim
+            sc = hf[:, d:d + 2].t().contiguous()
+            if k < len(chain) - 1:
+                x = layer.gat_forward_from_transform(hf[:, :d], sc, b, m, rows=self.own_rows)
+                nxt, send = chain[k + 1], self._xchg_more[k]["send"][parity]
+                dn, n = nxt.out_dim, hi - lo
+                _, sc2 = nxt.gat_transform_rows(x[lo:hi], h=send[:n, :dn])
+                send[:n, dn:dn + 2].copy_(sc2.t())
+                return send[:n]
+            rows = None
+            if self.prune_last and 4 * self.B < self.init_x[0].shape[0]:
+                rows = self._scored_rows(parity)
+            m.acts.append(layer.gat_forward_from_transform(hf[:, :d], sc, b, m, rows=rows))
+            m.acts.append(self.upper_layers[-1](m.acts[-1], b, m))
+            return m.acts[-1]
+
+    def _scored_rows(self, parity):
+        """The interaction rows this step's pairs read, each ONCE, as a static-shape list (ascending, duplicates replaced
+        by -1: blgnn_gat_aggregate skips negative entries).  Pairs are drawn from the interaction EDGES, so a row appears
+        in proportion to its degree: at configs[3] the raw [2 B] list of a rank's 8 192 pairs made the pruned last layer
+        gather more edges than the whole graph has (632 us against 340 for every row; rocprofv3, emulated N = 8)."""
+        s = torch.sort(self.ids_dev[parity].view(-1)).values
+        dup = torch.cat([torch.zeros(1, dtype=torch.bool, device=s.device), s[1:] == s[:-1]])
+        return torch.where(dup, torch.full_like(s, -1), s)
 
     def _prune_layer(self):
         """The last interaction-level conv layer when it is a plain GAT layer directly in front of the pair scorer and
@@ -437,10 +520,13 @@ class BiLevelEngine(object):
                 with torch.cuda.graph(g, stream=side):
                     self.pooled[p] = self.lower(p, readout=not defer)
                 self.g_lower[p] = g
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
-                    self.outs[p] = self.upper(p, readout=defer)
-                self.g_upper[p] = g
+                gs = []
+                for k in range(self.n_upper_segments):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side):
+                        self.outs[p] = self.upper(p, readout=defer, segment=k if self.shard_upper else None)
+                    gs.append(g)
+                self.g_upper[p] = gs
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if self.overlap and not self.parity_streams and self._masked is None:
@@ -449,11 +535,13 @@ class BiLevelEngine(object):
                 ser = False
                 if self.world <= 1:                      # (with ranks every rank must decide alike: left to the caller)
                     t = []
-                    for gr in (self.g_lower[0], self.g_upper[0]):
+                    for grs in ([self.g_lower[0]], self.g_upper[0]):
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        gr.replay()
+                        for gr in grs:
+                            gr.replay()
                         e0.record()
-                        gr.replay()
+                        for gr in grs:
+                            gr.replay()
                         e1.record()
                         torch.cuda.synchronize()
                         t.append(e0.elapsed_time(e1))
@@ -479,7 +567,7 @@ class BiLevelEngine(object):
             self._feed(which, 0)
             self.g_lower[0].replay()
             self.exchange(self.pooled[0], 0)
-            self.g_upper[0].replay()
+            self._replay_upper(0)
             return self.outs[0]
         p = self.step_no & 1
         self.step_no += 1
@@ -503,10 +591,18 @@ class BiLevelEngine(object):
         with torch.cuda.stream(su):
             su.wait_event(self.ev_ids[p])
             su.wait_event(self.ev_lower[p])
-            self.g_upper[p].replay()
+            self._replay_upper(p)
             self.ev_upper[p] = torch.cuda.Event()
             self.ev_upper[p].record(su)
         return self.outs[p]
+
+    def _replay_upper(self, p):
+        """the interaction pass's captured piece(s) on the current stream, ``shard_upper``'s all-gathers between them"""
+        gs = self.g_upper[p]
+        for k, g in enumerate(gs):
+            g.replay()
+            if k < len(gs) - 1:
+                self.exchange(None, p, stage=k + 1)
 
     def synchronize(self):
         if self.overlap and self.stream_l is not None:

@@ -357,9 +357,10 @@ class NodeEmbedding(nn.Module):
         with torch.no_grad():
             return ops.gat_transform(x, self.conv.weight, self.conv.att, h=h)
 
-    def gat_forward_from_transform(self, h, sc, batch_data, model, out=None):
+    def gat_forward_from_transform(self, h, sc, batch_data, model, out=None, rows=None):
         """Graph half of the layer on the full transformed table; same result as ``forward`` on the rows
-        the table was transformed from."""
+        the table was transformed from.  ``rows`` (int64, device): only these target rows are computed (a rank's own
+        rows of a target-row-sharded interaction level, or the rows the scored pairs read)."""
         assert self.type == 'gat'
         csr = self._graph(batch_data).csr()
         slopes = prelu_slopes(self._cache, "prelu", self.act, self.out_dim)
@@ -367,7 +368,7 @@ class NodeEmbedding(nn.Module):
         with torch.no_grad():
             x = ops.gat_from_transform(csr, h, sc, self.conv.bias, group=getattr(FLAGS, "gat_softmax_group", "src"),
                                        slope=self.conv.negative_slope, act=act_name(self.act), act_param=slopes,
-                                       bn_scale=scale, bn_shift=shift, out=out)
+                                       bn_scale=scale, bn_shift=shift, out=out, rows=rows)
             model.store_layer_output(self, x)
             if self.normalize:
                 x = ops.l2_normalize_rows(x)

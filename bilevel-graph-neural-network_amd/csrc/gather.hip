@@ -639,7 +639,8 @@ __global__ void __launch_bounds__(256) k_gather_wide(const GatherArgs A) {
     extern __shared__ float4 part4[];            // [4][d4] float4, then the parked edges
     const int nrows = A.row_list ? A.n_list : A.n;
     for (int it = blockIdx.x; it < nrows; it += gridDim.x) {
-        const int row = A.row_list ? (int)A.row_list[it] : it;         // (a row listed twice is computed twice: same values)
+        const int row = A.row_list ? (int)A.row_list[it] : it;         // (a row listed twice is computed twice: same values;
+        if (row < 0) continue;                                         //  a negative entry is skipped: a de-duplicated list's padding)
         const int deg = A.rowptr[row + 1] - A.rowptr[row];            // (uniform: scalar loads)
         if (deg < A.deg_min || deg > A.deg_max) continue;
         wide_row<MODE, LG, CH>(A, row, part4);
@@ -684,7 +685,7 @@ __global__ void __launch_bounds__(256) k_gather_wave(const GatherArgs A) {
             __syncthreads();
             for (int it = base + threadIdx.x; it < base + HUB_QUEUE && it < hi; it += blockDim.x) {
                 const int r = A.row_list ? (int)A.row_list[it] : it;
-                if (A.rowptr[r + 1] - A.rowptr[r] > A.deg_max) queue[1 + atomicAdd(&queue[0], 1)] = r;
+                if (r >= 0 && A.rowptr[r + 1] - A.rowptr[r] > A.deg_max) queue[1 + atomicAdd(&queue[0], 1)] = r;
             }
             __syncthreads();
             const int found = queue[0];
@@ -699,6 +700,7 @@ __global__ void __launch_bounds__(256) k_gather_wave(const GatherArgs A) {
     for (int k = 0; k < CH; ++k) ok[k] = (l + k * LG) < d4;
     for (int it = (blockIdx.x - A.hub_blocks) * 4 + wid; it < nrows; it += waves) {
         const int row = __builtin_amdgcn_readfirstlane(A.row_list ? (int)A.row_list[it] : it);
+        if (row < 0) continue;                                  // (padding of a de-duplicated row list)
         const int e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
         if (e1 - e0 > A.deg_max) continue;                      // a hub: the hub role's
         EdgeCtx<MODE> ctx;
@@ -877,7 +879,10 @@ constexpr int64_t WIDE_MEAN_DEGREE = 12;
 // ... and, on graphs with at least this many rows to compute, one-wavefront-per-row with the hubs behind it (k_gather_wave);
 // below it a launch has fewer rows than the chip has wavefront slots and the workgroup-per-row kernel's 256 threads per
 // row are the parallelism there is (DrugBank interaction level: 1 326 rows)
+// (a row LIST of a large graph -- a rank's own target rows, the rows a batch scores -- takes the wavefront kernel from 8 192 rows:
+// 12.5 k listed rows of configs[3]: 122 us workgroup-per-row; BLGNN_GATHER_WAVE_MIN_ROWS overrides both for A/B runs)
 constexpr int WAVE_ROW_MIN_ROWS = 16384;
+constexpr int WAVE_LIST_MIN_ROWS = 8192;
 
 // row magnitudes of a finished result merged into amax by atomic maximum (fallback of the variants without an amax epilogue)
 __global__ void __launch_bounds__(256) k_row_absmax_merge(const float *__restrict__ y, int64_t ldy, int n, int d,
@@ -900,8 +905,10 @@ static int dispatch(const GatherArgs &A, int64_t nnz, bool extra_aligned, hipStr
                      aligned16(A.x) && aligned16(A.y) && extra_aligned;
     const int d4 = A.d / 4;
     static const bool wave_rows = [] { const char *e = getenv("BLGNN_GATHER_WAVE"); return !(e && e[0] == '0'); }();   // (A/B switch)
+    static const int min_env = [] { const char *e = getenv("BLGNN_GATHER_WAVE_MIN_ROWS"); return e ? atoi(e) : 0; }();
+    const int wave_min = min_env > 0 ? min_env : (A.row_list && A.n >= WAVE_ROW_MIN_ROWS ? WAVE_LIST_MIN_ROWS : WAVE_ROW_MIN_ROWS);
     if (wave_rows && MODE != MODE_RELU && vec && d4 <= 128 && nnz >= WIDE_MEAN_DEGREE * (int64_t)A.n &&
-        (A.row_list ? A.n_list : A.n) >= WAVE_ROW_MIN_ROWS) {
+        (A.row_list ? A.n_list : A.n) >= wave_min) {
         if (d4 <= 16) launch_wave<MODE, 16, 1>(A, s);
         else if (d4 <= 32) launch_wave<MODE, 32, 1>(A, s);
         else if (d4 <= 64) launch_wave<MODE, 64, 1>(A, s);

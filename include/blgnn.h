@@ -272,10 +272,11 @@ int blgnn_gat_softmax_stats(const int32_t *rowptr, const int32_t *col, int64_t n
  * accumulate != 0 adds into y (NodeModelAggrByEdge: model/layers_meta.py:74-79);
  * the epilogue (act, then affine) is applied to the value being written.
  * rows / num_rows (optional): compute only the target rows rows[0 .. num_rows) (int64 device array, duplicates
- * allowed) and leave every other row of y untouched -- the LAST interaction-level layer feeds only the rows the pair
- * scorer reads (model/layers_link_pred.py:56-61), so a rank of a sharded job need not compute the others.  Honoured
- * by the high-degree kernels (one workgroup per row; one wavefront per row from 16 384 rows on); low-degree graphs
- * compute every row.  stats_packed (optional): the packed statistics blgnn_gat_softmax_stats wrote (same values). */
+ * allowed -- computed again, same values --, negative entries skipped: the padding of a de-duplicated list) and leave
+ * every other row of y untouched -- the LAST interaction-level layer feeds only the rows the pair scorer reads
+ * (model/layers_link_pred.py:56-61), and a rank of a target-row-sharded job computes its own rows of the others.
+ * Honoured by the high-degree kernels (one workgroup per row; one wavefront per row from 16 384 rows on, from 8 192
+ * listed rows of a graph that large); low-degree graphs compute every row.  stats_packed (optional): the packed statistics blgnn_gat_softmax_stats wrote (same values). */
 int blgnn_gat_aggregate(const int32_t *rowptr, const int32_t *col, int64_t nnz,
                         const float *h, int64_t ldh, const float *s_dst,
                         const float *s_src, const float *mx, const float *den,

@@ -421,6 +421,13 @@ def test_engine_last_interaction_layer_pruned_to_scored_rows(device):
     keep = torch.zeros(n, dtype=torch.bool, device=device)
     keep[rows] = True
     assert torch.equal(part[keep], full[keep]) and bool((part[~keep] == -7.0).all())
+    # negative entries (the padding of the engine's de-duplicated list) are skipped
+    rows = torch.tensor([-1, 5, -1, -1, 17, n - 1, -1], dtype=torch.int64, device=device)
+    part = torch.full_like(full, -7.0)
+    ops.gat_from_transform(csr, h, sc, bias, act="relu", out=part, rows=rows)
+    keep = torch.zeros(n, dtype=torch.bool, device=device)
+    keep[rows[rows >= 0]] = True
+    assert torch.equal(part[keep], full[keep]) and bool((part[~keep] == -7.0).all())
 
 
 def test_engine_follows_weight_updates_after_capture(device):
@@ -513,3 +520,64 @@ def test_fused_readout_is_the_default_and_matches_the_separate_launch(device):
             out = eng.step(0)
         eng.synchronize()
         assert max_err(out, ref) < 1e-6
+
+
+def test_engine_target_row_sharded_interaction_level_one_rank(device):
+    """``BiLevelEngine(shard_upper=True)`` at one rank (own rows = every row, no collective): each interaction layer's graph
+    half through the row list, the next layer's row-wise half on those rows, three captured pieces per pass -- the
+    same kernels on the same rows as the replicated pass: bit for bit its scores (the last layer pruned or not)"""
+    from blgnn.engine import BiLevelEngine
+    ds = blgnn.make_synthetic(400, 9000, seed=29, device=device)
+    flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin",
+                             higher_level_gnn_type="gat", D_lower=128, D_higher=128, device=device,
+                             fuse_readout=False)   # bitwise comparisons: no float atomics in the readout
+    model, data = build(flags, ds, seed=9)
+    lower = blgnn.BatchData(all_molecule_pairs(ds.molecules.gids), ds, is_train=False, ignore_pairs=True)
+    g = ds.interaction_combo_nxgraph
+    g.init_x = torch.zeros((ds.num_graphs(), 5 * 128), device=device)
+    ds.init = True
+    uppers = [blgnn.BatchData(_pairs(ds, 48, seed=k), ds, is_train=False) for k in range(2)]
+    plain = BiLevelEngine(model, lower, uppers, g, use_graph=False, prune_last=False)
+    refs = [plain.eager_step(i).clone() for i in range(2)]
+    for use_graph in (False, True):
+        for prune in (False, True):
+            with BiLevelEngine(model, lower, uppers, g, use_graph=use_graph, exchange_transformed=True,
+                               shard_upper=True, prune_last=prune) as eng:
+                assert eng.shard_upper and eng.n_upper_segments == 3
+                eng.capture()
+                for i in range(4):
+                    out = eng.step(i)
+                    eng.synchronize()
+                    assert torch.equal(out, refs[i % 2]), (use_graph, prune, i)
+
+
+def test_engine_target_row_sharded_interaction_level_two_ranks(device):
+    """the same with TWO ranks sharing the GPU over gloo (tests/shard_upper_worker.py): a rank computes its own target
+    rows of every interaction layer but the last, all-gathers the next layer's transformed rows, and scores -- equal to
+    the replicated pass and to a one-rank engine over all drugs"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import conftest
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": "0", "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port)})
+        procs.append(subprocess.Popen([sys.executable, os.path.join(conftest.ROOT, "tests", "shard_upper_worker.py")],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=400)[0])
+    finally:
+        for p in procs:                                   # exact PIDs started here
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d:\n%s" % (r, outs[r][-3000:])

@@ -553,6 +553,17 @@ def test_convs_one_wavefront_per_row_with_hub_rows(device, d):
         untouched = torch.ones(n, dtype=torch.bool, device=device)
         untouched[rows] = False
         assert float((part[untouched] + 7.0).abs().max()) == 0.0
+        # a shorter list (>= 8 192 listed rows of a graph this large still take the wavefront kernel) holding both hubs,
+        # with negative padding entries: skipped by the wavefront role and by the hub scan
+        some = torch.as_tensor(np.concatenate([[17, 4242, 103], rng.choice(n, size=9000, replace=False)]), device=device)
+        padded = torch.where(torch.arange(some.numel(), device=device) % 5 == 3, torch.full_like(some, -1), some)
+        part = ops.gat_conv(csr, dv(x), dv(W), dv(att), dv(b), group=group, rows=padded,
+                            out=torch.full((n, d), -7.0, device=device))
+        kept = padded[padded >= 0]
+        assert torch.equal(part[kept], got[kept])
+        untouched = torch.ones(n, dtype=torch.bool, device=device)
+        untouched[kept] = False
+        assert float((part[untouched] + 7.0).abs().max()) == 0.0
     ref = oracle.gcn_conv(x.double(), ei, W.double(), b.double())
     assert max_err(ops.gcn_conv(csr, dv(x), dv(W), dv(b)), ref) < TOL
     ref = oracle.scatter_add(x[ei[1]].double(), ei[0], n) + x.double()
