@@ -1160,6 +1160,10 @@ def main():
     if os.environ.get("BLGNN_BENCH_RENDEZVOUS_ONLY"):
         return rendezvous_only(args)
     import torch                                            # noqa: F401  (first GPU-touching import of a rank)
+    # host-side torch ops (the batch builder's index arithmetic) on the cores this process may use, shared among the ranks of
+    # the node: by default torch sizes its intra-op pool by the VISIBLE cores (256 on a box that grants 16) and the
+    # oversubscribed pool stalls for tens of ms at a time
+    torch.set_num_threads(max(1, usable_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
     D = Dist(args)
     transform = "f32" if args.exact_f32 else args.transform
     if args.train:

@@ -84,8 +84,10 @@ class TrainStep(object):
                              % (self.num_pairs, len(batch.batch_gids)))
         host = self.scorer.pair_row_ids(batch)
         self._copied.synchronize()               # the previous batch's H2D copies have read the pinned staging buffers
-        self._host_ids.copy_(torch.from_numpy(np.ascontiguousarray(host.T)))
-        self._host_labels.copy_(torch.from_numpy(np.asarray(batch._labels, dtype=np.float32)))
+        # (plain memcpys into the pinned blocks: Tensor.copy_ on large CPU tensors goes through torch's intra-op thread pool,
+        # which stalls for tens of ms on a box whose CPU quota is a fraction of its visible cores -- blgnn/engine.py _feed)
+        np.copyto(self._host_ids.numpy(), host.T)
+        np.copyto(self._host_labels.numpy(), np.asarray(batch._labels, dtype=np.float32))
         self.ids.copy_(self._host_ids, non_blocking=True)
         self.labels.copy_(self._host_labels, non_blocking=True)
         self._copied.record(torch.cuda.current_stream(self.device))
