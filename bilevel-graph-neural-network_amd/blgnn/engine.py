@@ -285,11 +285,10 @@ class BiLevelEngine(object):
         # either writes -- by default both parities' sweeps share stream L and both interaction passes stream U, which
         # would hide such a buffer).  Not a speed-up: measured 0.34 vs 0.20 ms per step at configs[1] in round 3.
         # ``serialize``: sweep and interaction pass of consecutive steps on ONE stream (still double-buffered, still
-        # asynchronous to the host, the id copies still on their own stream).  None = decided at capture time from the two
-        # graphs' own durations: when the sweep is >= 4x the interaction pass there is little to gain from running them side
-        # by side (configs[3] at N = 1: 20.7 + 2.1 ms in a row against 22.4 overlapped) and something to lose -- beside the
-        # sweep's tens of thousands of workgroups the short pass's kernels can starve until it outlasts the sweep and stalls
-        # the next-but-one (22 -> 27-35 ms in episodes; profiles/r04_cfg3_emulated_ranks.txt).
+        # asynchronous to the host, the id copies still on their own stream).  Opt-in (None = False = side by side, see
+        # capture()); BLGNN_ENGINE_SERIALIZE = 0 | 1 overrides None for A/B runs.
+        if serialize is None and os.environ.get("BLGNN_ENGINE_SERIALIZE") in ("0", "1"):      # (A/B switch)
+            serialize = os.environ["BLGNN_ENGINE_SERIALIZE"] == "1"
         self.serialize = serialize
         self.parity_streams = bool(parity_streams and self.overlap)
         self.serialized = False
@@ -536,20 +535,11 @@ class BiLevelEngine(object):
         if self.overlap and not self.parity_streams and self._masked is None:
             ser = self.serialize
             if ser is None:
+                # side by side by default.  (First half of round 4 decided this from the two graphs' durations and ran sweep
+                # and pass in a row when the sweep was >= 4x the pass: the 27-35 ms "episodes" that motivated it were the host
+                # stalling in _feed's staging copy -- see there -- not starvation on the device.  With that fixed, 3-second
+                # windows at configs[3]: N = 1 23.04 side by side vs 23.43 in a row, emulated N = 2 11.90 vs 12.30, no episode.)
                 ser = False
-                if self.world <= 1:                      # (with ranks every rank must decide alike: left to the caller)
-                    t = []
-                    for grs in ([self.g_lower[0]], self.g_upper[0]):
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        for gr in grs:
-                            gr.replay()
-                        e0.record()
-                        for gr in grs:
-                            gr.replay()
-                        e1.record()
-                        torch.cuda.synchronize()
-                        t.append(e0.elapsed_time(e1))
-                    ser = t[0] >= 4.0 * t[1] and t[0] >= 2.0     # (ms; sweeps below 2 ms keep the overlap they were tuned with)
             self.serialized = bool(ser)
             self._su = [self._sl[0], self._sl[1]] if self.serialized else [self.stream_u, self.stream_u]
 
