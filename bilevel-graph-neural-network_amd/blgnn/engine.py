@@ -481,7 +481,12 @@ class BiLevelEngine(object):
         by -1: blgnn_gat_aggregate skips negative entries).  Pairs are drawn from the interaction EDGES, so a row appears
         in proportion to its degree: at configs[3] the raw [2 B] list of a rank's 8 192 pairs made the pruned last layer
         gather more edges than the whole graph has (632 us against 340 for every row; rocprofv3, emulated N = 8)."""
-        s = torch.sort(self.ids_dev[parity].view(-1)).values
+        return self.dedup_rows(self.ids_dev[parity].view(-1))
+
+    @staticmethod
+    def dedup_rows(ids):
+        """int64 ids [m] -> [m]: the distinct ids ascending, every repeat replaced by -1 (static shape: capturable)"""
+        s = torch.sort(ids).values
         dup = torch.cat([torch.zeros(1, dtype=torch.bool, device=s.device), s[1:] == s[:-1]])
         return torch.where(dup, torch.full_like(s, -1), s)
 

@@ -198,3 +198,17 @@ def test_readout_styles_wiring(monkeypatch, node_aggr):
         model.acts.append(layer(model.acts[-1], bd, model))
     for got, r in zip(model.acts[1:], ref[1:]):
         assert max_err(got, r) < 1e-5
+
+
+def test_engine_scored_rows_are_listed_once():
+    """BiLevelEngine.dedup_rows (the row list of the pruned last interaction layer): every distinct id once, ascending,
+    repeats replaced by -1 -- the gather kernels skip negative entries -- and the shape of the input kept (capturable)"""
+    from blgnn.engine import BiLevelEngine
+    rng = np.random.default_rng(0)
+    for m, hi in ((1, 5), (64, 7), (4096, 300), (4096, 10 ** 6)):
+        ids = torch.as_tensor(rng.integers(0, hi, size=m))
+        out = BiLevelEngine.dedup_rows(ids)
+        assert out.shape == ids.shape and out.dtype == torch.int64
+        kept = out[out >= 0]
+        assert torch.equal(kept, torch.unique(ids))                   # distinct, ascending
+        assert int((out == -1).sum()) == m - kept.numel()
