@@ -574,8 +574,11 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
         tag = {"f16x3": "gin_layer_h3", "bf16x6": "gin_layer_x6", "f32": "gin_layer"}[mode]
         sel = [i for i, n in enumerate(names) if n == mode]
         if sel:
-            res["roofline"] = roofline_of(kname, [ms[i] for i in sel], [work[i] for i in sel], mult, peak,
-                                          pmc_traffic(tag + ("_cfg%d" % cfg_id if cfg_id != 1 else "")))
+            sfx = "_cfg%d" % cfg_id if cfg_id != 1 else ""
+            traffic = pmc_traffic(tag + sfx)
+            if traffic is None:                          # (the d = 256 kernel's passes are filed under their width)
+                traffic = pmc_traffic("%s_d%d%s" % (tag, d, sfx))
+            res["roofline"] = roofline_of(kname, [ms[i] for i in sel], [work[i] for i in sel], mult, peak, traffic)
     if want_roofline and rank == 0:
         gms, gwork, _ = gtimer.result()
         if gms:
