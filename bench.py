@@ -89,6 +89,10 @@ def parse():
     ap.add_argument("--no-shard-upper", action="store_true",
                     help="N > 1, >= 32 768 interaction rows: keep the interaction level replicated on every rank instead of "
                          "target-row sharded (blgnn/engine.py shard_upper)")
+    ap.add_argument("--rccl-one-rank", action="store_true",
+                    help="N = 1, bi-level configs: initialise RCCL with one rank and run the engine's all-gathers (the sweep's, "
+                         "and with >= 32 768 interaction rows the sharded interaction pass's) as real RCCL calls between "
+                         "the captured graphs -- what the collectives cost a step apart from the link transfer")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="profiling aid: build rank 0's share of an N-GPU run on one GPU (no collective)")
     ap.add_argument("--fuse-lower", action="store_true",
@@ -326,6 +330,16 @@ class Dist(object):
                                         device_id=torch.device(self.device))
             else:
                 dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+        self.one_rank_pg = False
+        if self.world == 1 and getattr(args, "rccl_one_rank", False):
+            sock = socket.socket()
+            sock.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+            sock.close()
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(self.device))
+            self.one_rank_pg = True
+        if self.world > 1:
             joined = torch.ones(1, device=self.device if self.backend == "nccl" else "cpu")
             dist.all_reduce(joined)
             if int(joined.item()) != self.world:
@@ -346,6 +360,7 @@ class Dist(object):
     def close(self):
         if self.world > 1:
             self.dist.barrier()
+        if self.world > 1 or self.one_rank_pg:
             self.dist.destroy_process_group()
 
 
@@ -470,10 +485,11 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
                            use_graph=not args.no_graph, overlap=not args.no_overlap,
                            fuse_lower=(False if args.no_fuse_lower else (True if args.fuse_lower else None)),
                            readout_with_upper=args.readout_with_upper,
-                           lower_cus_per_xcd=lower_cus, exchange_transformed=(True if emu else None),
+                           lower_cus_per_xcd=lower_cus, exchange_transformed=(True if (emu or D.one_rank_pg) else None),
                            prune_last=(True if (emu and not args.no_prune_last) else (False if args.no_prune_last else None)),
                            shard_upper=(False if args.no_shard_upper else
-                                        (True if (emu and ds.num_graphs() >= 32768) else None)))
+                                        (True if ((emu or D.one_rank_pg) and ds.num_graphs() >= 32768) else None)),
+                           collective=(True if (D.one_rank_pg and not emu) else None))
     try:
         engine.capture()
         # a fresh random batch of pair ids every step (src/sampler.py:120-131), drawn ahead of the timed

@@ -134,7 +134,7 @@ class BiLevelEngine(object):
 
     def __init__(self, model, lower_batch, upper_batches, graph, sharded=None, world_size=1,
                  use_graph=True, overlap=True, fuse_lower=None, readout_with_upper=None, lower_cus_per_xcd=None,
-                 exchange_transformed=None, prune_last=None, parity_streams=False, serialize=None, shard_upper=None):
+                 exchange_transformed=None, prune_last=None, parity_streams=False, serialize=None, shard_upper=None, collective=None):
         from .config import FLAGS
         k = FLAGS.last_lower_lyr_num
         self.model = model
@@ -256,6 +256,13 @@ class BiLevelEngine(object):
         # configs[3]) in exchange for (N - 1) / N of L - 1 gathers; the last layer computes the rows its pairs read from
         # the full table (``prune_last``).  Default: N > 1 and >= 32 768 interaction rows (below that the extra
         # collectives' launch latency is the same size as the compute they save: configs[1]).
+        # ``collective=True``: call the all-gather even with ONE rank (a process group must be initialised and the rank must own
+        # every interaction row) -- the RCCL call path, its stream ordering against the captured graphs included, on a box
+        # with a single GPU (tests/shard_upper_worker.py)
+        self.collective = bool(self.world > 1 or collective)
+        if self.collective and self.world <= 1:
+            if not self.exchange_transformed or self.local_hi - self.local_lo != base.shape[0]:
+                raise ValueError("blgnn: collective=True at one rank needs exchange_transformed and every interaction row local")
         chain = self.upper_layers[1:-1]
         can_shard = (self.exchange_transformed and len(chain) >= 2 and
                      all(isinstance(l, NodeEmbedding) and l.type == 'gat' and l.higher_level and not l.normalize
@@ -391,9 +398,9 @@ class BiLevelEngine(object):
             dest = self.h_full[parity] if self.exchange_transformed else self.init_x[parity]
         if not self.exchange_transformed:
             send[:pooled.shape[0]].copy_(pooled)               # (transformed rows were written into ``send``)
-        if self.world > 1:
+        if self.collective:
             import torch.distributed as dist
-            dist.all_gather_into_tensor(recv, send, group=self.sharded.group)
+            dist.all_gather_into_tensor(recv, send, group=self.sharded.group if self.sharded is not None else None)
         else:                                                  # one rank (tests, --emulate-world): its own rows only
             n = self.local_hi - self.local_lo
             dest[self.local_lo:self.local_hi].copy_(send[:n])

@@ -1,5 +1,6 @@
 """Worker of tests/test_gpu_model.py::test_engine_target_row_sharded_interaction_level_two_ranks: one of two ranks that
-share the GPU over gloo (RCCL refuses two ranks on one device; the engine's sharding and collective code is the same).
+share the GPU over gloo (RCCL refuses two ranks on one device; the engine's sharding and collective code is the same) --
+and of ::test_engine_collectives_over_rccl_one_rank: ONE rank whose all-gathers are real RCCL calls (BLGNN_WORKER_BACKEND=nccl).
 Each rank runs the same pair batches through the engine with the interaction level replicated and target-row sharded
 (``BiLevelEngine(shard_upper=...)``) and compares its scores; rank 0 also compares with a one-rank engine over all drugs."""
 
@@ -22,9 +23,15 @@ from helpers import build
 
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("BLGNN_WORKER_BACKEND", "gloo")
     device = "cuda:0"
     torch.cuda.set_device(0)
+    if backend == "nccl":
+        # ONE rank over RCCL: the engine's collectives run as RCCL calls (``collective=True``) between its captured graphs
+        assert world == 1
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(device))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     ds = blgnn.make_synthetic(230, 2600, seed=31, device=device)
     flags = blgnn.make_flags("lower_level_gnn_higher_level", lower_level_gnn_type="gin", higher_level_gnn_type="gat",
                              D_lower=128, D_higher=128, device=device, fuse_readout=False)
@@ -42,7 +49,7 @@ def main():
     for shard in (False, True):
         for use_graph in (False, True):
             with BiLevelEngine(model, lower, uppers, g, sharded=sharded, world_size=world, use_graph=use_graph,
-                               shard_upper=shard) as eng:
+                               shard_upper=shard, exchange_transformed=True, collective=True) as eng:
                 assert eng.shard_upper == shard and eng.exchange_transformed
                 assert eng.n_upper_segments == (3 if shard else 1)
                 eng.capture()
@@ -66,8 +73,11 @@ def main():
     vs_plain = 0.0
     for i in range(3):
         vs_plain = max(vs_plain, float((plain.eager_step(i) - outs[(True, True)][i]).abs().max()))
-    print("rank %d: sharded vs replicated max |diff| %.3e, vs one-rank %.3e" % (rank, worst, vs_plain), flush=True)
+    print("rank %d (%s, world %d): sharded vs replicated max |diff| %.3e, vs one-rank %.3e"
+          % (rank, backend, world, worst, vs_plain), flush=True)
     assert worst <= 2e-6 and vs_plain <= 2e-6, (worst, vs_plain)
+    if world == 1:
+        assert worst == 0.0 and vs_plain == 0.0          # one rank: the same kernels on the same rows
     dist.barrier()
     dist.destroy_process_group()
 

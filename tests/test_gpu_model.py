@@ -551,10 +551,7 @@ def test_engine_target_row_sharded_interaction_level_one_rank(device):
                     assert torch.equal(out, refs[i % 2]), (use_graph, prune, i)
 
 
-def test_engine_target_row_sharded_interaction_level_two_ranks(device):
-    """the same with TWO ranks sharing the GPU over gloo (tests/shard_upper_worker.py): a rank computes its own target
-    rows of every interaction layer but the last, all-gathers the next layer's transformed rows, and scores -- equal to
-    the replicated pass and to a one-rank engine over all drugs"""
+def _run_shard_workers(world, backend):
     import os
     import socket
     import subprocess
@@ -565,10 +562,11 @@ def test_engine_target_row_sharded_interaction_level_two_ranks(device):
     port = sock.getsockname()[1]
     sock.close()
     procs = []
-    for r in range(2):
+    for r in range(world):
         env = dict(os.environ)
-        env.update({"RANK": str(r), "LOCAL_RANK": "0", "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1",
-                    "MASTER_PORT": str(port)})
+        env.update({"RANK": str(r), "LOCAL_RANK": "0", "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "BLGNN_WORKER_BACKEND": backend})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(conftest.ROOT, "tests", "shard_upper_worker.py")],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -581,3 +579,20 @@ def test_engine_target_row_sharded_interaction_level_two_ranks(device):
                 p.kill()
     for r, p in enumerate(procs):
         assert p.returncode == 0, "rank %d:\n%s" % (r, outs[r][-3000:])
+    return outs
+
+
+def test_engine_collectives_over_rccl_one_rank(device):
+    """the engine's all-gathers as REAL RCCL calls (one rank, backend nccl, ``BiLevelEngine(collective=True)``): the
+    collective of the sweep and the two of the target-row-sharded interaction pass, issued between replays of the captured
+    graphs on the engine's two streams, eager and captured, sharded and replicated -- bit for bit the scores of an engine
+    without any collective.  (Two ranks cannot share one GPU under RCCL: the two-rank test below runs over gloo.)"""
+    out = _run_shard_workers(1, "nccl")[0]
+    assert "nccl, world 1" in out
+
+
+def test_engine_target_row_sharded_interaction_level_two_ranks(device):
+    """the same with TWO ranks sharing the GPU over gloo (tests/shard_upper_worker.py): a rank computes its own target
+    rows of every interaction layer but the last, all-gathers the next layer's transformed rows, and scores -- equal to
+    the replicated pass and to a one-rank engine over all drugs"""
+    _run_shard_workers(2, "gloo")
