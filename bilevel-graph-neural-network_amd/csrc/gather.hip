@@ -850,8 +850,10 @@ template <int MODE, int LG, int CH>
 static void launch_vec(const GatherArgs &A, hipStream_t s) {
     constexpr int RPW = WAVE / LG;
     const int64_t waves = ((int64_t)A.n + RPW - 1) / RPW;
+    static const int cap_env = [] { const char *e = getenv("BLGNN_GATHER_VEC_BLOCKS"); return e ? atoi(e) : 0; }();    // (A/B switch)
+    const int64_t cap = cap_env > 0 ? cap_env : 256 * 16;
     int64_t blocks = (waves + 3) / 4;
-    if (blocks > 256 * 16) blocks = 256 * 16;   // grid-stride beyond 16 blocks per CU
+    if (blocks > cap) blocks = cap;             // grid-stride beyond 16 blocks per CU
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((k_gather<MODE, LG, CH>), dim3((unsigned)blocks), dim3(256), 0, s, A);
 }
