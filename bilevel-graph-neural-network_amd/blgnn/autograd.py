@@ -171,17 +171,36 @@ def gat_conv(x, weight, att, bias, csr, group="src", slope=0.2, act="identity"):
     return _GatConv.apply(x, weight, att, bias, csr, group, slope, act)
 
 
+def _symmetric_edge_weights(csr, w):
+    """True when the per-edge weights ``w`` (CSR order) satisfy w(i, j) == w(j, i) on the symmetric graph ``csr`` (index
+    arithmetic on the device, one host sync; called once per training forward that brings edge weights)."""
+    counts = (csr.rowptr[1:] - csr.rowptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(csr.n, device=csr.col.device), counts)
+    cols = csr.col.long()
+    fwd = torch.argsort(rows * csr.n + cols)
+    bwd = torch.argsort(cols * csr.n + rows)
+    return bool(torch.equal(w[fwd], w[bwd]))
+
+
 class _GcnConv(torch.autograd.Function):
-    """y = act(A_hat (x W) + b), GCNConv (model/layers.py:23,52) without edge weights; A_hat = D^-1/2 (A + I) D^-1/2 is
-    symmetric, so the gradient of the propagation is the propagation itself."""
+    """y = act(A_hat (x W) + b), GCNConv (model/layers.py:23,48-52); A_hat = D^-1/2 (A_w + I) D^-1/2 is symmetric -- without
+    edge weights, or with weights that are the same in both directions of an edge --, so the gradient of the propagation
+    is the propagation itself.  The weights are data (no gradient); asymmetric ones are refused."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, csr, act):
+    def forward(ctx, x, weight, bias, csr, act, edge_weight=None):
         _check_act(act)
         x, weight = x.detach(), weight.detach()
         csr.require_symmetric("GCNConv backward")
-        y = ops.gcn_conv(csr, x, weight, bias.detach(), None, act=act)
-        ctx.csr, ctx.act = csr, act
+        if edge_weight is not None:
+            edge_weight = edge_weight.detach().reshape(-1).contiguous()
+            if edge_weight.numel() != csr.nnz:
+                raise ValueError("blgnn: GCNConv expects one weight per edge (%d), got %d" % (csr.nnz, edge_weight.numel()))
+            if not _symmetric_edge_weights(csr, edge_weight):
+                raise ValueError("blgnn: GCNConv backward needs w(i, j) == w(j, i): the backward pass reuses the forward "
+                                 "operator as its transpose")
+        y = ops.gcn_conv(csr, x, weight, bias.detach(), edge_weight, act=act)
+        ctx.csr, ctx.act, ctx.edge_weight = csr, act, edge_weight
         ctx.save_for_backward(x, weight, y)
         return y
 
@@ -190,15 +209,15 @@ class _GcnConv(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         dy = dy.contiguous()
         g = dy if ctx.act == "identity" else ops.act_backward(dy, y, ctx.act)
-        dh = ops.gcn_propagate(ctx.csr, g)
+        dh = ops.gcn_propagate(ctx.csr, g, ctx.edge_weight)
         dx = ops.linear(dh, ops.transpose(weight.contiguous()), transform="f32") if ctx.needs_input_grad[0] else None
         dw = ops.grad_weight(x, dh) if ctx.needs_input_grad[1] else None
         db = ops.col_reduce(g, "sum") if ctx.needs_input_grad[2] else None
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def gcn_conv(x, weight, bias, csr, act="identity"):
-    return _GcnConv.apply(x, weight, bias, csr, act)
+def gcn_conv(x, weight, bias, csr, act="identity", edge_weight=None):
+    return _GcnConv.apply(x, weight, bias, csr, act, edge_weight)
 
 
 class _MultiEdgeGat(torch.autograd.Function):

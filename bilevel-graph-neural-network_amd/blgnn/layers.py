@@ -339,9 +339,9 @@ class NodeEmbedding(nn.Module):
             x = ag.gat_conv(ins, self.conv.weight, self.conv.att, self.conv.bias, csr,
                             group=getattr(FLAGS, "gat_softmax_group", "src"), slope=self.conv.negative_slope, act=act)
         else:
-            if getattr(batch_data.merge_data['merge'], "edge_attr", None) is not None:
-                raise NotImplementedError("blgnn: GCN layers train without edge weights (none of the shipped configs has any)")
-            x = ag.gcn_conv(ins, self.conv.weight, self.conv.bias, csr, act=act)
+            # (model/layers.py:48-52: the LOWER merge's edge_attr is the edge weight, for upper layers too; data, no gradient)
+            x = ag.gcn_conv(ins, self.conv.weight, self.conv.bias, csr, act=act,
+                            edge_weight=getattr(batch_data.merge_data['merge'], "edge_attr", None))
         x = after(x)
         if self.bn:
             x = ag.batch_norm_train(x, self.bn)

@@ -977,3 +977,34 @@ def test_link_pred_dot_product_trains(device):
     (got.view(-1) * wgt.to(device)).sum().backward()
     assert max_err(got.view(-1), ref.view(-1)) < TOL
     assert max_err(zd.grad, zr.grad) < TOL
+
+
+def test_gcn_conv_edge_weights_forward_backward(device):
+    """GCNConv with per-edge weights (model/layers.py:48-52 hands the merge's edge_attr to the conv): forward and every
+    gradient against fp64 autograd on the oracle for weights that are equal in both directions of an edge; weights that
+    are not are refused in training (the backward reuses the forward operator as its transpose)"""
+    from test_gpu_ops import rand_graph
+    n, K, d = 400, 40, 64
+    ei = rand_graph(n, 5, seed=3, self_loops=False, isolated=3)
+    lo, hi = torch.minimum(ei[0], ei[1]), torch.maximum(ei[0], ei[1])
+    ew = ((lo * 7919 + hi * 104729) % 1000).float() / 1000 + 0.25          # w(i, j) == w(j, i)
+    g = torch.Generator().manual_seed(2)
+    x, w, b = torch.randn(n, K, generator=g), torch.randn(K, d, generator=g) / K ** 0.5, torch.randn(d, generator=g)
+    dy = torch.randn(n, d, generator=g)
+    xr, wr, br = _leaf(x), _leaf(w), _leaf(b)
+    ref = torch.tanh(oracle.ops.gcn_conv(xr, ei, wr, br, edge_weight=ew.double()))
+    ref.backward(dy.double())
+    csr = ops.csr_from_edge_index(ei.to(device), n)
+    with torch.no_grad():
+        fwd = ops.gcn_conv(csr, x.to(device), w.to(device), b.to(device), ew.to(device), act="tanh")
+    assert max_err(fwd, ref) < TOL
+    xd, wd, bd = _leaf(x, device), _leaf(w, device), _leaf(b, device)
+    got = ag.gcn_conv(xd, wd, bd, csr, act="tanh", edge_weight=ew.to(device))
+    got.backward(dy.to(device))
+    assert max_err(got, ref) < TOL
+    for a, r in ((xd, xr), (wd, wr), (bd, br)):
+        assert max_err(a.grad, r.grad) < TOL
+    skew = ew.clone()
+    skew[0] += 0.5
+    with pytest.raises(ValueError):
+        ag.gcn_conv(_leaf(x, device), wd, bd, csr, act="tanh", edge_weight=skew.to(device))
