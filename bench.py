@@ -137,7 +137,9 @@ def parse():
     ap.add_argument("--gmn-match-streams", type=int, default=1, choices=(1, 2),
                     help="GMN configs: side streams of the cross-graph attention's size-class kernels")
     ap.add_argument("--gmn-streams", type=int, default=1,
-                    help="GMN configs: consecutive steps (independent pair batches) alternate over this many streams")
+                    help="GMN configs: consecutive steps (independent pair batches) alternate over this many streams, i.e. "
+                         "that many forwards are in flight (2: 14.35 -> 14.04 ms/step at configs[2], checked against the same "
+                         "batch run alone; default 1 = one forward at a time, the regime the roofline pass times kernels in)")
     ap.add_argument("--no-fuse-readout", action="store_true",
                     help="bi-level configs: a separate segment-reduce launch instead of the readout fused into the "
                          "GIN layers' epilogues")
@@ -758,6 +760,13 @@ def run_gmn(cfg_id, args, D, transform, steps, warmup, min_seconds, want_rooflin
         elapsed, blocks = timed_blocks(run_block, min_seconds)
         preds = last[0]
         assert preds.shape[0] == batch and bool(torch.isfinite(preds).all())
+        if lanes is not None:
+            # the pipelined steps compute what a step alone computes: the last timed step's batch again, alone on the default
+            # stream (equal to the last-bit variation of the fused readouts' float atomics)
+            alone = forward(counter[0] - 1)
+            torch.cuda.synchronize()
+            dev_ = float((alone - preds).abs().max()) / max(1.0, float(alone.abs().max()))
+            assert dev_ < 1e-6, "pipelined forward differs from the same batch run alone: %.3e" % dev_
         shared_active = getattr(model.acts[1], "_blgnn_shared", None) is not None      # (too few repeats: not taken)
         pooled_active = getattr(model.acts[-3], "_blgnn_pooled", None) is not None     # (the last propagator's output)
         # the same steps on the plain path -- every copy of a molecule computed, node rows of every layer written and a

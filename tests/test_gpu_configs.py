@@ -123,3 +123,36 @@ def test_config3_bignn_d256_sharded_equals_unsharded(device, upper):
     gathered = torch.cat(parts, dim=0)
     # not bit-identical: tile edges move with the batch composition
     assert max_err(gathered, init_full) < 1e-6
+
+
+def test_gmn_forwards_pipelined_over_two_streams_equal_sequential(device):
+    """bench.py's GMN default keeps TWO forwards of independent pair batches in flight (consecutive steps alternate
+    over two streams; each launch stream has its own attention side streams, no work buffer outlives a call): the
+    predictions of every pipelined step equal those of the same batch run alone on the default stream, to the last-bit
+    variation of the fused readouts' float atomics"""
+    d = 256
+    ds = blgnn.make_synthetic(300, 3000, shape="drugcombo", seed=31, device=device, num_edge_types=2)
+    flags = blgnn.make_flags("lower_level_gmn", dataset="drugcombo", lower_level_gnn_type="gin", D_lower=d, device=device)
+    model, data = build(flags, ds, seed=32, num_hyper_edge_feat=3)
+    rng = np.random.default_rng(4)
+    batches = [blgnn.BatchData(ds.pair_gids[rng.choice(len(ds.pair_gids), size=1100, replace=False)], ds, is_train=False,
+                               unique_graphs=False).prepare() for _ in range(3)]
+    layers = model.layers[:-1]
+
+    def forward(b):
+        model.acts = [b.merge_data['merge'].x]
+        with torch.no_grad():
+            for layer in layers:
+                model.acts.append(layer(model.acts[-1], b, model))
+        return model.acts[-1]
+    refs = [forward(b).clone() for b in batches]
+    torch.cuda.synchronize()
+    lanes = [torch.cuda.Stream(device=device) for _ in range(2)]
+    outs = []
+    for i in range(12):
+        with torch.cuda.stream(lanes[i % 2]):
+            outs.append(forward(batches[i % 3]))
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        assert o.shape == (1100, 3)
+        assert max_err(o, refs[i % 3].double().cpu()) < 1e-6, i
