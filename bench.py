@@ -490,7 +490,8 @@ def run_bilevel(cfg_id, args, D, transform, steps, warmup, min_seconds, want_roo
                            lower_cus_per_xcd=lower_cus, exchange_transformed=(True if (emu or D.one_rank_pg) else None),
                            prune_last=(True if (emu and not args.no_prune_last) else (False if args.no_prune_last else None)),
                            shard_upper=(False if args.no_shard_upper else
-                                        (True if ((emu or D.one_rank_pg) and ds.num_graphs() >= 32768) else None)),
+                                        (True if ((emu or D.one_rank_pg) and (ds.num_graphs() >= 32768 or os.environ.get("BLGNN_BENCH_SHARD_UPPER") == "1"))
+                                         else None)),
                            collective=(True if (D.one_rank_pg and not emu) else None))
     try:
         engine.capture()
