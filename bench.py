@@ -1242,6 +1242,23 @@ def main():
                 extra["configs_3_n1"] = {"value": r3["value"], "unit": "pairs/s", "ms_per_step": r3["ms_per_step"],
                                          "workload": r3["config"]["workload"], "roofline": r3.get("roofline"),
                                          "interaction_gather": r3.get("interaction_gather")}
+                # one rank's share of an N-GPU job at the same config, compute only (no collective runs; the interaction
+                # level target-row sharded as it is with ranks): what the scaling projection in DESIGN section 6 rests on
+                import copy
+                emu_rows = {}
+                for n_emu in (2, 4, 8):
+                    fresh_pools()
+                    a2 = copy.copy(args)
+                    a2.emulate_world = n_emu
+                    re_ = run_bilevel(3, a2, D, transform, 10, 3, 0.2, want_roofline=False)
+                    emu_rows[str(n_emu)] = {"ms_per_step": re_["ms_per_step"],
+                                            "interaction_level_ms": re_["config"]["interaction_level_ms"],
+                                            "interaction_level": re_["config"].get("interaction_level")}
+                extra["configs_3_emulated_ranks"] = {
+                    "what": "bench.py --config 3 --emulate-world N: ONE rank's share of an N-GPU job on this GPU -- 1/N of the "
+                            "molecules swept, its own target rows of the interaction level, 1/N of the pairs -- with every "
+                            "all-gather replaced by a local copy of the rank's own block.  Compute-only projection, NOT a "
+                            "multi-GPU measurement", "ranks": emu_rows}
             fresh_pools()
             r5 = run_bilevel(5, args, D, transform, 50, 10, 0.3, want_roofline=False)
             extra["drugcombo_interaction_level"] = {
