@@ -870,7 +870,8 @@ static void launch_wide(const GatherArgs &A, hipStream_t s) {
 template <int MODE, int LG, int CH>
 static void launch_wave(GatherArgs A, hipStream_t s) {
     const int rows = A.row_list ? A.n_list : A.n;
-    A.deg_min = 0; A.deg_max = WAVE_ROW_HUB_DEGREE; A.hub_blocks = HUB_BLOCKS;
+    static const int hub_env = [] { const char *e = getenv("BLGNN_GATHER_HUB_DEGREE"); return e ? atoi(e) : 0; }();     // (A/B switch)
+    A.deg_min = 0; A.deg_max = hub_env > 0 ? hub_env : WAVE_ROW_HUB_DEGREE; A.hub_blocks = HUB_BLOCKS;
     static const int cap_env = [] { const char *e = getenv("BLGNN_GATHER_WAVE_BLOCKS"); return e ? atoi(e) : 0; }();   // (A/B switch)
     const int cap = cap_env > 0 ? cap_env : 256 * 32;          // (configs[3]: 1 024 blocks 354 us, 2 048 344, 4 096 338, 8 192 331, 32 768 335)
     const int blocks = HUB_BLOCKS + ((rows + 3) / 4 < cap ? (rows + 3) / 4 : cap);
