@@ -871,10 +871,12 @@ template <int MODE, int LG, int CH>
 static void launch_wave(GatherArgs A, hipStream_t s) {
     const int rows = A.row_list ? A.n_list : A.n;
     static const int hub_env = [] { const char *e = getenv("BLGNN_GATHER_HUB_DEGREE"); return e ? atoi(e) : 0; }();     // (A/B switch)
-    A.deg_min = 0; A.deg_max = hub_env > 0 ? hub_env : WAVE_ROW_HUB_DEGREE; A.hub_blocks = HUB_BLOCKS;
+    static const int hubb_env = [] { const char *e = getenv("BLGNN_GATHER_HUB_BLOCKS"); return e ? atoi(e) : 0; }();    // (A/B switch)
+    const int hub_blocks = hubb_env > 0 ? hubb_env : HUB_BLOCKS;
+    A.deg_min = 0; A.deg_max = hub_env > 0 ? hub_env : WAVE_ROW_HUB_DEGREE; A.hub_blocks = hub_blocks;
     static const int cap_env = [] { const char *e = getenv("BLGNN_GATHER_WAVE_BLOCKS"); return e ? atoi(e) : 0; }();   // (A/B switch)
     const int cap = cap_env > 0 ? cap_env : 256 * 32;          // (configs[3]: 1 024 blocks 354 us, 2 048 344, 4 096 338, 8 192 331, 32 768 335)
-    const int blocks = HUB_BLOCKS + ((rows + 3) / 4 < cap ? (rows + 3) / 4 : cap);
+    const int blocks = hub_blocks + ((rows + 3) / 4 < cap ? (rows + 3) / 4 : cap);
     hipLaunchKernelGGL((k_gather_wave<MODE, LG, CH>), dim3(blocks), dim3(256),
                        (size_t)A.d * 16 + WIDE_EDGES * 8 + (HUB_QUEUE + 1) * sizeof(int), s, A);
 }
