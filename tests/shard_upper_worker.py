@@ -29,7 +29,14 @@ def main():
     if backend == "nccl":
         # ONE rank over RCCL: the engine's collectives run as RCCL calls (``collective=True``) between its captured graphs
         assert world == 1
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(device))
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(device))
+            probe = torch.ones(4, device=device)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+        except Exception as e:                       # RCCL cannot come up on this box: the caller skips (exit code 77)
+            print("RCCL_INIT_FAILED: %r" % (e,), flush=True)
+            sys.exit(77)
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     ds = blgnn.make_synthetic(230, 2600, seed=31, device=device)

@@ -577,6 +577,8 @@ def _run_shard_workers(world, backend):
         for p in procs:                                   # exact PIDs started here
             if p.poll() is None:
                 p.kill()
+    if backend == "nccl" and any(p.returncode == 77 for p in procs):
+        pytest.skip("RCCL did not initialise on this box: " + outs[0][-300:])
     for r, p in enumerate(procs):
         assert p.returncode == 0, "rank %d:\n%s" % (r, outs[r][-3000:])
     return outs
